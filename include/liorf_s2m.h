@@ -1,0 +1,180 @@
+/*
+ * liorf_s2m.h — C ABI of the MI355X (gfx950) scan-to-map registration path.
+ *
+ * This is the drop-in boundary for ONE path of jimmyshe/liorf's mapOptimization
+ * node: scan2MapOptimization() -> surfOptimization() + combineOptimizationCoeffs()
+ * + LMOptimization() + transformUpdate()   (reference src/mapOptmization.cpp:1295-1363).
+ * Everything behind these entry points runs as hand-written HIP kernels; there is
+ * no CPU fallback (calls fail with S2M_ERR_NO_DEVICE when no gfx950 device is usable).
+ *
+ * Conventions
+ *   - plain C types only: pointers, sizes, fixed-width ints, float/double.
+ *   - every function returns an int status: 0 = S2M_OK, < 0 = error. The reference's
+ *     three soft conditions (no map :1297, <= 30 features :1300, < 50 correspondences
+ *     :1178) are NOT errors: status 0, pose unchanged, counters set in s2m_result.
+ *   - point clouds are handed over as arrays of records of `stride_bytes` bytes whose
+ *     first 12 bytes are float x,y,z. pcl::PointXYZI (the reference's PointType,
+ *     include/utility.h:61) is stride 32; tightly packed xyz is stride 12.
+ *   - pose vectors are float[6] = {roll, pitch, yaw, x, y, z}: the layout of the
+ *     reference's transformTobeMapped[6] (src/mapOptmization.cpp:134, :337-351).
+ *   - a handle is single-caller (the reference serialises this path under `mtx`,
+ *     :252); separate handles are independent (one per GPU / per stream).
+ *   - no C++ exception crosses this boundary.
+ */
+#ifndef LIORF_S2M_H
+#define LIORF_S2M_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2M_ABI_VERSION 1
+
+/* status codes */
+#define S2M_OK                 0
+#define S2M_ERR_INVALID_ARG   -1
+#define S2M_ERR_NO_DEVICE     -2   /* no usable HIP device / kernel image for it   */
+#define S2M_ERR_HIP           -3   /* a HIP runtime call failed (see s2m_last_error) */
+#define S2M_ERR_NO_SCAN       -4   /* *_resident call without s2m_set_scan          */
+#define S2M_ERR_CAPACITY      -5   /* grid / buffer limit exceeded                   */
+
+/* ScanContext descriptor shape (reference include/Scancontext.h:82-84) */
+#define S2M_SC_NUM_RING    20
+#define S2M_SC_NUM_SECTOR  60
+
+typedef struct s2m_context* s2m_handle;
+
+/*
+ * Parameters. s2m_default_params() fills in the reference's constants; the
+ * comments give the reference line each one restates (src/mapOptmization.cpp
+ * unless another file is named).
+ */
+typedef struct s2m_params {
+    uint32_t struct_size;     /* sizeof(s2m_params), set by s2m_default_params          */
+    int32_t  device_id;       /* HIP device ordinal (default 0)                          */
+    void*    stream;          /* optional caller-owned hipStream_t; NULL = library makes one */
+    int32_t  k_neighbors;     /* 5: nearestKSearch(pointSel, 5, ...)              :1087  */
+    double   gate_sq;         /* 1.0: pointSearchSqDis[4] < 1.0                   :1097  */
+    double   plane_tol;       /* 0.2: |n.p_j + d| > 0.2 rejects the plane         :1118  */
+    double   weight_scale;    /* 0.9: s = 1 - 0.9*|pd2|/sqrt(range)               :1127  */
+    double   weight_min;      /* 0.1: keep iff s > 0.1                            :1135  */
+    int32_t  min_corr;        /* 50: laserCloudSelNum < 50 -> return false        :1178  */
+    int32_t  min_feats;       /* 30: laserCloudSurfLastDSNum > 30                 :1300  */
+    int32_t  max_iter;        /* 30: iterCount < 30                               :1304  */
+    float    eig_thresh;      /* 100: eignThre[6]                                 :1252  */
+    double   conv_deg;        /* 0.05: deltaR < 0.05 (degrees)                    :1289  */
+    double   conv_cm;         /* 0.05: deltaT < 0.05 (centimetres)                :1289  */
+    float    z_tol;           /* z_tollerance, FLT_MAX default  include/utility.h:230     */
+    float    rot_tol;         /* rotation_tollerance, FLT_MAX   include/utility.h:231     */
+    int32_t  imu_type;        /* imuType (0: 6-axis, 1: 9-axis) include/utility.h:211     */
+    float    imu_rpy_weight;  /* imuRPYWeight 0.01              include/utility.h:218     */
+    int32_t  early_exit;      /* 1 = break when LMOptimization() returns true (:1313);
+                                 0 = always run max_iter iterations (benchmark mode)      */
+} s2m_params;
+
+/*
+ * The cloud_info fields the hot path reads (reference msg/cloud_info.msg:10-16;
+ * read at src/mapOptmization.cpp:1325-1342 by transformUpdate()). NULL is
+ * accepted wherever this struct is taken and means imuAvailable = 0.
+ */
+typedef struct s2m_imu_init {
+    int64_t imuAvailable;     /* cloud_info.imuAvailable */
+    float   imuRollInit;      /* cloud_info.imuRollInit  */
+    float   imuPitchInit;     /* cloud_info.imuPitchInit */
+    float   imuYawInit;       /* cloud_info.imuYawInit (not read on this path) */
+} s2m_imu_init;
+
+/* What scan2MapOptimization() leaves behind in the node's members. */
+typedef struct s2m_result {
+    int32_t iters_run;        /* LM iterations executed (1..max_iter), 0 if skipped       */
+    int32_t converged;        /* 1 if LMOptimization() returned true                      */
+    int32_t is_degenerate;    /* isDegenerate (:139) -> pose.covariance[0] (:1724-1727)   */
+    int32_t n_sel_last;       /* laserCloudSelNum of the last executed iteration          */
+    int32_t skipped;          /* 0 ran; 1 no map (:1297); 2 not enough features (:1300)   */
+    float   pose[6];          /* transformTobeMapped after transformUpdate()              */
+    float   affine[12];       /* incrementalOdometryAffineBack, row-major 3x4 (:1352)     */
+} s2m_result;
+
+/* One record per executed LM iteration (s2m_get_trace). */
+typedef struct s2m_iter_trace {
+    int32_t n_sel;            /* correspondences kept by surfOptimization()               */
+    int32_t stepped;          /* 0 if n_sel < min_corr (pose unchanged), else 1           */
+    float   delta[6];         /* matX after the degeneracy projection (:1266-1278)        */
+    float   pose[6];          /* transformTobeMapped after this iteration                 */
+    float   deltaR, deltaT;   /* :1280-1287                                               */
+} s2m_iter_trace;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+const char* s2m_version(void);
+int  s2m_default_params(s2m_params* p);
+int  s2m_create(const s2m_params* p, s2m_handle* out);
+int  s2m_destroy(s2m_handle h);
+const char* s2m_last_error(s2m_handle h);       /* valid until the next call on h */
+
+/* ---- inputs ------------------------------------------------------------- */
+/* Replaces kdtreeSurfFromMap->setInputCloud(laserCloudSurfFromMapDS) (:1302):
+ * uploads the local surf map and builds the device neighbour-search index.
+ * n == 0 is allowed and models "cloudKeyPoses3D->points.empty()" (:1297). */
+int  s2m_set_map(s2m_handle h, const void* pts, size_t n, size_t stride_bytes);
+/* Same, for a map that already lives in device memory (hipMalloc'd). */
+int  s2m_set_map_device(s2m_handle h, const void* d_pts, size_t n, size_t stride_bytes);
+/* Uploads laserCloudSurfLastDS (lidar-frame points) for the *_resident calls. */
+int  s2m_set_scan(s2m_handle h, const void* pts, size_t n, size_t stride_bytes);
+int  s2m_set_scan_device(s2m_handle h, const void* d_pts, size_t n, size_t stride_bytes);
+
+/* ---- the path ----------------------------------------------------------- */
+/* scan2MapOptimization() (:1295-1321) on host buffers: s2m_set_scan() followed
+ * by s2m_optimize_resident(). pose is in/out (= transformTobeMapped). */
+int  s2m_optimize(s2m_handle h, const void* scan, size_t n, size_t stride_bytes,
+                  float pose[6], const s2m_imu_init* imu, s2m_result* out);
+/* The <= max_iter x {surfOptimization, combineOptimizationCoeffs, LMOptimization}
+ * loop (:1304-1315) plus transformUpdate() (:1317) on the resident scan + map.
+ * Runs entirely on the device; one synchronisation at the end. */
+int  s2m_optimize_resident(s2m_handle h, float pose[6], const s2m_imu_init* imu,
+                           s2m_result* out);
+/* Asynchronous form for throughput measurement: enqueue the same device work on
+ * the handle's stream and return without synchronising; s2m_optimize_collect()
+ * synchronises and fills the outputs of the most recent launch. */
+int  s2m_optimize_launch(s2m_handle h, const float pose[6]);
+int  s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu,
+                          s2m_result* out);
+/* Per-iteration records of the last optimize call; returns the count (<= cap). */
+int  s2m_get_trace(s2m_handle h, s2m_iter_trace* out, int cap);
+
+/* ---- observation hooks (used by the parity tests) ----------------------- */
+/* One surfOptimization() pass (:1074-1143) at `pose` on the resident scan + map.
+ * Outputs are in the scan's ORIGINAL point order; any may be NULL.
+ *   idx5   [n*5]  neighbour indices into the map as given to s2m_set_map, ascending d2
+ *   d2_5   [n*5]  squared distances (fp32, ((dx^2+dy^2)+dz^2))
+ *   flag   [n]    laserCloudOriSurfFlag (:1138)
+ *   coeff4 [n*4]  coeffSelSurfVec: s*pa, s*pb, s*pc, s*pd2 (:1130-1133); 0 if !flag
+ * idx5/d2_5 are defined for queries whose 5th neighbour passes the gate
+ * (d2 < gate_sq); for the others idx5 = -1 (the reference never reads them). */
+int  s2m_surf_optimization(s2m_handle h, const float pose[6],
+                           int32_t* idx5, float* d2_5, uint8_t* flag, float* coeff4);
+/* matAtA / matAtB / laserCloudSelNum of one iteration at `pose` (:1182-1239). */
+int  s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6],
+                   int32_t* n_sel);
+/* Raw device time (ms) of the last s2m_optimize* call, measured with HIP events
+ * on the handle's stream; and of the last s2m_set_map / s2m_set_scan index build. */
+int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float* set_scan_ms);
+/* Benchmark helper: runs `reps` back-to-back launches of the per-iteration
+ * registration kernel (kNN + plane + Jacobian + block reduction) at `pose`
+ * between two HIP events on the handle's stream; returns mean ms per launch. */
+int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float* ms_per_launch);
+
+/* ---- ScanContext descriptor (BASELINE config 5) ------------------------- */
+/* SCManager::makeScancontext + makeRingkeyFromScancontext
+ * (reference include/Scancontext.cpp:151-211): desc is 20x60 row-major doubles,
+ * ringkey 20 doubles. Points are host records as above. */
+int  s2m_make_scancontext(s2m_handle h, const void* pts, size_t n, size_t stride_bytes,
+                          double desc[S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR],
+                          double ringkey[S2M_SC_NUM_RING]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIORF_S2M_H */
