@@ -1,0 +1,672 @@
+// s2m_abi.hip — host side of the gfx950 scan-to-map path and its C ABI (include/liorf_s2m.h).
+//
+// Owns the device memory (grow-only, sized by the actual point counts), builds the map's
+// uniform-grid index and the scan's locality order on the device, and runs the whole
+// <= max_iter LM loop as one captured hipGraph of {k_register, k_finalize} pairs so that a
+// scan costs one graph launch and one synchronisation.  There is no CPU fallback: without a
+// gfx950 device every entry point fails with S2M_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+
+#include "s2m_host_math.hpp"
+#include "s2m_kernels.hpp"
+
+using namespace s2m;
+
+namespace {
+
+struct DevBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+inline uint32_t host_f2ord(float f) { uint32_t u; memcpy(&u, &f, 4); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+inline float host_ord2f(uint32_t o) { uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o; float f; memcpy(&f, &u, 4); return f; }
+
+}  // namespace
+
+struct s2m_context {
+    s2m_params prm{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // map side
+    DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
+    // scan side
+    DevBuf raw_scan, qx, qy, qz, qperm, q_counts, q_cell_start, q_cell_of, q_rank_of;
+    // shared
+    DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, sc_bins, sc_out;
+
+    DevCtx hctx{};
+    bool ctx_dirty = true;
+    size_t n_m = 0, n_q = 0;
+    bool have_scan = false;
+
+    // pinned host staging
+    DevState* h_state = nullptr;       // [2]: [0] upload, [1] download
+    s2m_iter_trace* h_trace = nullptr; // [kMaxIter]
+    uint32_t* h_mm = nullptr;          // [6]
+    DevCtx* h_ctx_pin = nullptr;
+    double* h_sc = nullptr;            // [1200 + 20]
+
+    // state that persists across scans in the reference node (:139-140)
+    int persist_degenerate = 0;
+    float persist_matP[36] = { 0 };
+
+    std::map<int, hipGraphExec_t> graphs;
+    bool use_graph = true;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+    float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
+    bool opt_pending = false;
+    int pending_skipped = 0;
+    float pending_pose_in[6] = { 0 };
+    s2m_iter_trace last_trace[kMaxIter];
+    int last_trace_n = 0;
+};
+
+namespace {
+
+int fail(s2m_context* h, int code, const char* what, hipError_t e = hipSuccess)
+{
+    if (h) {
+        h->err = what;
+        if (e != hipSuccess) { h->err += ": "; h->err += hipGetErrorString(e); }
+    }
+    return code;
+}
+
+#define S2M_HIP(h, call)                                                     \
+    do {                                                                     \
+        hipError_t e__ = (call);                                             \
+        if (e__ != hipSuccess) return fail((h), S2M_ERR_HIP, #call, e__);   \
+    } while (0)
+
+int ensure(s2m_context* h, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return S2M_OK;
+    size_t want = bytes + bytes / 4 + 256;          // grow-only with slack
+    if (b.p) { S2M_HIP(h, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    S2M_HIP(h, hipMalloc(&b.p, want));
+    b.cap = want;
+    h->ctx_dirty = true;
+    return S2M_OK;
+}
+
+int upload_ctx(s2m_context* h)
+{
+    if (!h->ctx_dirty) return S2M_OK;
+    *h->h_ctx_pin = h->hctx;
+    S2M_HIP(h, hipMemcpyAsync(h->dctx.p, h->h_ctx_pin, sizeof(DevCtx), hipMemcpyHostToDevice, h->stream));
+    // the pinned mirror may be rewritten by the next call: make the copy complete first
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    h->ctx_dirty = false;
+    return S2M_OK;
+}
+
+// exclusive scan of counts[0..n) into out[0..n], out[n] = total
+int device_exclusive_scan(s2m_context* h, const int32_t* counts, int32_t* out, int n, int total)
+{
+    const int nb = (n + 1023) / 1024;
+    int rc = ensure(h, h->block_sums, sizeof(int32_t) * (size_t)(nb + 1));
+    if (rc) return rc;
+    int32_t* sums = h->block_sums.as<int32_t>();
+    hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, h->stream, counts, out, sums, n);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sums, nb);
+    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, h->stream, out, (const int32_t*)sums, n, total);
+    S2M_HIP(h, hipGetLastError());
+    return S2M_OK;
+}
+
+// bounding box of the finite points (device reduction + 24-byte readback)
+int device_bbox(s2m_context* h, const unsigned char* d_pts, size_t stride, int n, float mn[3], float mx[3])
+{
+    for (int d = 0; d < 3; d++) { h->h_mm[d] = 0xffffffffu; h->h_mm[3 + d] = 0u; }
+    S2M_HIP(h, hipMemcpyAsync(h->mm.p, h->h_mm, 24, hipMemcpyHostToDevice, h->stream));
+    const int blocks = std::min((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, h->stream, d_pts, stride, n, h->mm.as<uint32_t>());
+    S2M_HIP(h, hipGetLastError());
+    S2M_HIP(h, hipMemcpyAsync(h->h_mm, h->mm.p, 24, hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    for (int d = 0; d < 3; d++) {
+        if (h->h_mm[d] == 0xffffffffu || h->h_mm[3 + d] == 0u) { mn[d] = 0.0f; mx[d] = 0.0f; }   // no finite value
+        else { mn[d] = host_ord2f(h->h_mm[d]); mx[d] = host_ord2f(h->h_mm[3 + d]); }
+    }
+    return S2M_OK;
+}
+
+int check_records(s2m_context* h, const void* pts, size_t n, size_t stride)
+{
+    if (!h) return S2M_ERR_INVALID_ARG;
+    if (n > 0 && !pts) return fail(h, S2M_ERR_INVALID_ARG, "null point buffer");
+    if (stride < 12 || (stride & 3)) return fail(h, S2M_ERR_INVALID_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+    if ((reinterpret_cast<uintptr_t>(pts) & 3) != 0) return fail(h, S2M_ERR_INVALID_ARG, "point buffer must be 4-byte aligned");
+    if (n > (size_t)0x3fffffff) return fail(h, S2M_ERR_CAPACITY, "too many points");
+    return S2M_OK;
+}
+
+int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool on_device)
+{
+    int rc = check_records(h, pts, n, stride);
+    if (rc) return rc;
+    S2M_HIP(h, hipSetDevice(h->device));
+    S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
+    h->n_m = n;
+    h->hctx.n_m = (int32_t)n;
+    h->ctx_dirty = true;
+    if (n == 0) { h->t_set_map_ms = 0; return upload_ctx(h); }
+
+    const unsigned char* d_pts;
+    if (on_device) d_pts = static_cast<const unsigned char*>(pts);
+    else {
+        if ((rc = ensure(h, h->raw_map, n * stride))) return rc;
+        S2M_HIP(h, hipMemcpyAsync(h->raw_map.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+        d_pts = h->raw_map.as<unsigned char>();
+    }
+    float mn[3], mx[3];
+    if ((rc = device_bbox(h, d_pts, stride, (int)n, mn, mx))) return rc;
+
+    // cell edge: every map point with fp32 d2 < gate_sq of a query lies in the 3x3x3 block
+    // around the query's cell once E >= sqrt(gate_sq) plus a margin that covers the fp32
+    // rounding of (v - o) * inv_e (<= 2.4e-5 cells at |v - o| <= 200).
+    double E = std::sqrt(h->prm.gate_sq) * (1.0 + 1.0 / 1024.0);
+    GridDesc g{};
+    for (int attempt = 0; attempt < 32; attempt++) {
+        const float Ef = (float)E;
+        g.inv_e = 1.0f / Ef;
+        g.ox = mn[0] - Ef; g.oy = mn[1] - Ef; g.oz = mn[2] - Ef;
+        double nx = std::floor(((double)mx[0] - g.ox) * g.inv_e) + 2.0;
+        double ny = std::floor(((double)mx[1] - g.oy) * g.inv_e) + 2.0;
+        double nz = std::floor(((double)mx[2] - g.oz) * g.inv_e) + 2.0;
+        if (nx * ny * nz <= (double)(1 << 27) && nx < 65536 && ny < 65536 && nz < 65536) {
+            g.nx = (int)nx; g.ny = (int)ny; g.nz = (int)nz; g.ncells = g.nx * g.ny * g.nz;
+            break;
+        }
+        E *= 2.0;     // coarser cells stay correct (only more candidates per query)
+        g.ncells = 0;
+    }
+    if (g.ncells <= 0) return fail(h, S2M_ERR_CAPACITY, "map extent too large for the search grid");
+
+    if ((rc = ensure(h, h->map_sorted, sizeof(float4) * n))) return rc;
+    if ((rc = ensure(h, h->m_counts, sizeof(int32_t) * ((size_t)g.ncells + 1)))) return rc;
+    if ((rc = ensure(h, h->m_cell_start, sizeof(int32_t) * ((size_t)g.ncells + 1)))) return rc;
+    if ((rc = ensure(h, h->m_cell_of, sizeof(int32_t) * n))) return rc;
+    if ((rc = ensure(h, h->m_rank_of, sizeof(int32_t) * n))) return rc;
+
+    S2M_HIP(h, hipMemsetAsync(h->m_counts.p, 0, sizeof(int32_t) * ((size_t)g.ncells + 1), h->stream));
+    const int nb = ((int)n + 255) / 256;
+    hipLaunchKernelGGL(k_bin_count<false>, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n, g,
+                       h->m_cell_of.as<int32_t>(), h->m_rank_of.as<int32_t>(), h->m_counts.as<int32_t>());
+    S2M_HIP(h, hipGetLastError());
+    if ((rc = device_exclusive_scan(h, h->m_counts.as<int32_t>(), h->m_cell_start.as<int32_t>(), g.ncells, (int)n))) return rc;
+    hipLaunchKernelGGL(k_scatter_map, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
+                       (const int32_t*)h->m_cell_of.as<int32_t>(), (const int32_t*)h->m_rank_of.as<int32_t>(),
+                       (const int32_t*)h->m_cell_start.as<int32_t>(), h->map_sorted.as<float4>());
+    S2M_HIP(h, hipGetLastError());
+
+    h->hctx.g = g;
+    h->hctx.map_sorted = h->map_sorted.as<float4>();
+    h->hctx.cell_start = h->m_cell_start.as<int32_t>();
+    h->ctx_dirty = true;
+    S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
+    if ((rc = upload_ctx(h))) return rc;            // synchronises: the caller's buffer is free again
+    S2M_HIP(h, hipEventElapsedTime(&h->t_set_map_ms, h->ev_c, h->ev_d));
+    return S2M_OK;
+}
+
+int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool on_device)
+{
+    int rc = check_records(h, pts, n, stride);
+    if (rc) return rc;
+    S2M_HIP(h, hipSetDevice(h->device));
+    S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
+    h->n_q = n; h->have_scan = true;
+    h->hctx.n_q = (int32_t)n;
+    int nblocks = (int)((n + kBlock - 1) / kBlock);
+    nblocks = ((nblocks + kBlocksQuantum - 1) / kBlocksQuantum) * kBlocksQuantum;
+    if (nblocks == 0) nblocks = kBlocksQuantum;
+    h->hctx.nblocks = nblocks;
+    h->ctx_dirty = true;
+    if ((rc = ensure(h, h->partials, sizeof(double) * kAcc * (size_t)nblocks))) return rc;
+    h->hctx.partials = h->partials.as<double>();
+    if (n == 0) { h->t_set_scan_ms = 0; return upload_ctx(h); }
+
+    const unsigned char* d_pts;
+    if (on_device) d_pts = static_cast<const unsigned char*>(pts);
+    else {
+        if ((rc = ensure(h, h->raw_scan, n * stride))) return rc;
+        S2M_HIP(h, hipMemcpyAsync(h->raw_scan.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+        d_pts = h->raw_scan.as<unsigned char>();
+    }
+    float mn[3], mx[3];
+    if ((rc = device_bbox(h, d_pts, stride, (int)n, mn, mx))) return rc;
+
+    // locality grid in the lidar frame (ordering only: any cell size is correct). Cells are
+    // numbered 4x4x4-tile-major so that consecutive lanes hold spatially compact points and a
+    // rigid transform keeps them compact in the map frame.
+    float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+    float Es = std::max(1.0f, ext / 500.0f);
+    GridDesc g{};
+    g.inv_e = 1.0f / Es; g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+    auto dim4 = [&](float lo, float hi) { int c = (int)std::floor((hi - lo) * g.inv_e) + 1; return ((c + 3) / 4) * 4; };
+    g.nx = dim4(mn[0], mx[0]); g.ny = dim4(mn[1], mx[1]); g.nz = dim4(mn[2], mx[2]);
+    g.ncells = g.nx * g.ny * g.nz;
+
+    if ((rc = ensure(h, h->qx, sizeof(float) * n))) return rc;
+    if ((rc = ensure(h, h->qy, sizeof(float) * n))) return rc;
+    if ((rc = ensure(h, h->qz, sizeof(float) * n))) return rc;
+    if ((rc = ensure(h, h->qperm, sizeof(int32_t) * n))) return rc;
+    if ((rc = ensure(h, h->q_counts, sizeof(int32_t) * ((size_t)g.ncells + 1)))) return rc;
+    if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * ((size_t)g.ncells + 1)))) return rc;
+    if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
+    if ((rc = ensure(h, h->q_rank_of, sizeof(int32_t) * n))) return rc;
+
+    S2M_HIP(h, hipMemsetAsync(h->q_counts.p, 0, sizeof(int32_t) * ((size_t)g.ncells + 1), h->stream));
+    const int nb = ((int)n + 255) / 256;
+    hipLaunchKernelGGL(k_bin_count<true>, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n, g,
+                       h->q_cell_of.as<int32_t>(), h->q_rank_of.as<int32_t>(), h->q_counts.as<int32_t>());
+    S2M_HIP(h, hipGetLastError());
+    if ((rc = device_exclusive_scan(h, h->q_counts.as<int32_t>(), h->q_cell_start.as<int32_t>(), g.ncells, (int)n))) return rc;
+    hipLaunchKernelGGL(k_scatter_scan, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
+                       (const int32_t*)h->q_cell_of.as<int32_t>(), (const int32_t*)h->q_rank_of.as<int32_t>(),
+                       (const int32_t*)h->q_cell_start.as<int32_t>(),
+                       h->qx.as<float>(), h->qy.as<float>(), h->qz.as<float>(), h->qperm.as<int32_t>());
+    S2M_HIP(h, hipGetLastError());
+
+    h->hctx.qx = h->qx.as<float>(); h->hctx.qy = h->qy.as<float>(); h->hctx.qz = h->qz.as<float>();
+    h->hctx.qperm = h->qperm.as<int32_t>();
+    h->ctx_dirty = true;
+    S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
+    if ((rc = upload_ctx(h))) return rc;
+    S2M_HIP(h, hipEventElapsedTime(&h->t_set_scan_ms, h->ev_c, h->ev_d));
+    return S2M_OK;
+}
+
+void fill_state(s2m_context* h, DevState* s, const float pose[6])
+{
+    memset(s, 0, sizeof(*s));
+    memcpy(s->pose, pose, 24);
+    host_pose_to_transform(pose, s->T, s->sc);
+    memcpy(s->matP, h->persist_matP, sizeof(s->matP));
+    s->isDegenerate = h->persist_degenerate;
+}
+
+int push_state(s2m_context* h, const float pose[6])
+{
+    fill_state(h, &h->h_state[0], pose);
+    S2M_HIP(h, hipMemcpyAsync(h->state.p, &h->h_state[0], sizeof(DevState), hipMemcpyHostToDevice, h->stream));
+    return S2M_OK;
+}
+
+int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
+{
+    auto it = h->graphs.find(nblocks);
+    if (it != h->graphs.end()) { *out = it->second; return S2M_OK; }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    const DevCtx* dc = h->dctx.as<DevCtx>();
+    S2M_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    for (int it2 = 0; it2 < h->prm.max_iter; it2++) {
+        hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, dc, it2, 0);
+    }
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "hipStreamEndCapture", e);
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "hipGraphInstantiate", e);
+    h->graphs[nblocks] = exec;
+    *out = exec;
+    return S2M_OK;
+}
+
+int launch_loop(s2m_context* h)
+{
+    const int nblocks = h->hctx.nblocks;
+    if (h->use_graph) {
+        hipGraphExec_t exec = nullptr;
+        int rc = get_graph(h, nblocks, &exec);
+        if (rc == S2M_OK) {
+            S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
+            S2M_HIP(h, hipGraphLaunch(exec, h->stream));
+            S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+            return S2M_OK;
+        }
+        h->use_graph = false;       // capture unsupported here: fall back to plain launches
+    }
+    const DevCtx* dc = h->dctx.as<DevCtx>();
+    S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
+    for (int it = 0; it < h->prm.max_iter; it++) {
+        hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, dc, it, 0);
+    }
+    S2M_HIP(h, hipGetLastError());
+    S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    return S2M_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* s2m_version(void) { return "liorf_amd s2m 0.1 (gfx950)"; }
+
+int s2m_default_params(s2m_params* p)
+{
+    if (!p) return S2M_ERR_INVALID_ARG;
+    memset(p, 0, sizeof(*p));
+    p->struct_size = (uint32_t)sizeof(s2m_params);
+    p->device_id = 0; p->stream = nullptr;
+    p->k_neighbors = 5; p->gate_sq = 1.0; p->plane_tol = 0.2; p->weight_scale = 0.9; p->weight_min = 0.1;
+    p->min_corr = 50; p->min_feats = 30; p->max_iter = 30; p->eig_thresh = 100.0f;
+    p->conv_deg = 0.05; p->conv_cm = 0.05; p->z_tol = FLT_MAX; p->rot_tol = FLT_MAX;
+    p->imu_type = 0; p->imu_rpy_weight = 0.01f; p->early_exit = 1;
+    return S2M_OK;
+}
+
+int s2m_create(const s2m_params* p, s2m_handle* out)
+{
+    if (!out) return S2M_ERR_INVALID_ARG;
+    *out = nullptr;
+    s2m_params prm;
+    if (p) {
+        if (p->struct_size != sizeof(s2m_params)) return S2M_ERR_INVALID_ARG;
+        prm = *p;
+    } else s2m_default_params(&prm);
+    if (prm.k_neighbors != 5 || prm.max_iter < 1 || prm.max_iter > kMaxIter || !(prm.gate_sq > 0.0)) return S2M_ERR_INVALID_ARG;
+
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || prm.device_id < 0 || prm.device_id >= count)
+        return S2M_ERR_NO_DEVICE;
+    if (hipSetDevice(prm.device_id) != hipSuccess) return S2M_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, prm.device_id) != hipSuccess) return S2M_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return S2M_ERR_NO_DEVICE;   // kernels are built for gfx950 only
+
+    s2m_context* h = new (std::nothrow) s2m_context();
+    if (!h) return S2M_ERR_HIP;
+    h->prm = prm; h->device = prm.device_id;
+    if (const char* e = getenv("S2M_NO_GRAPH")) h->use_graph = !(e[0] == '1');
+
+    auto bail = [&](int code) { s2m_destroy(h); return code; };
+    if (prm.stream) { h->stream = static_cast<hipStream_t>(prm.stream); h->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(S2M_ERR_HIP);
+        h->own_stream = true;
+    }
+    if (hipEventCreate(&h->ev_a) != hipSuccess || hipEventCreate(&h->ev_b) != hipSuccess ||
+        hipEventCreate(&h->ev_c) != hipSuccess || hipEventCreate(&h->ev_d) != hipSuccess) return bail(S2M_ERR_HIP);
+    if (hipHostMalloc((void**)&h->h_state, sizeof(DevState) * 2) != hipSuccess) return bail(S2M_ERR_HIP);
+    if (hipHostMalloc((void**)&h->h_trace, sizeof(s2m_iter_trace) * kMaxIter) != hipSuccess) return bail(S2M_ERR_HIP);
+    if (hipHostMalloc((void**)&h->h_mm, 64) != hipSuccess) return bail(S2M_ERR_HIP);
+    if (hipHostMalloc((void**)&h->h_ctx_pin, sizeof(DevCtx)) != hipSuccess) return bail(S2M_ERR_HIP);
+    if (hipHostMalloc((void**)&h->h_sc, sizeof(double) * 1220) != hipSuccess) return bail(S2M_ERR_HIP);
+    if (ensure(h, h->state, sizeof(DevState)) || ensure(h, h->trace, sizeof(s2m_iter_trace) * kMaxIter) ||
+        ensure(h, h->dctx, sizeof(DevCtx)) || ensure(h, h->mm, 64) ||
+        ensure(h, h->partials, sizeof(double) * kAcc * kBlocksQuantum) ||
+        ensure(h, h->sc_bins, sizeof(uint32_t) * 1200) || ensure(h, h->sc_out, sizeof(double) * 1220))
+        return bail(S2M_ERR_HIP);
+
+    memset(&h->hctx, 0, sizeof(h->hctx));
+    h->hctx.nblocks = kBlocksQuantum;
+    h->hctx.partials = h->partials.as<double>();
+    h->hctx.state = h->state.as<DevState>();
+    h->hctx.trace = h->trace.as<s2m_iter_trace>();
+    h->hctx.gate_sq = prm.gate_sq; h->hctx.plane_tol = prm.plane_tol; h->hctx.weight_scale = prm.weight_scale;
+    h->hctx.weight_min = prm.weight_min; h->hctx.conv_deg = prm.conv_deg; h->hctx.conv_cm = prm.conv_cm;
+    h->hctx.eig_thresh = prm.eig_thresh; h->hctx.min_corr = prm.min_corr; h->hctx.max_iter = prm.max_iter;
+    h->hctx.early_exit = prm.early_exit;
+    h->ctx_dirty = true;
+    if (upload_ctx(h) != S2M_OK) return bail(S2M_ERR_HIP);
+    *out = h;
+    return S2M_OK;
+}
+
+int s2m_destroy(s2m_handle h)
+{
+    if (!h) return S2M_OK;
+    hipSetDevice(h->device);
+    if (h->stream) hipStreamSynchronize(h->stream);
+    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
+                       &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
+                       &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->sc_bins, &h->sc_out };
+    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+    if (h->h_state) hipHostFree(h->h_state);
+    if (h->h_trace) hipHostFree(h->h_trace);
+    if (h->h_mm) hipHostFree(h->h_mm);
+    if (h->h_ctx_pin) hipHostFree(h->h_ctx_pin);
+    if (h->h_sc) hipHostFree(h->h_sc);
+    if (h->ev_a) hipEventDestroy(h->ev_a);
+    if (h->ev_b) hipEventDestroy(h->ev_b);
+    if (h->ev_c) hipEventDestroy(h->ev_c);
+    if (h->ev_d) hipEventDestroy(h->ev_d);
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+    delete h;
+    return S2M_OK;
+}
+
+const char* s2m_last_error(s2m_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int s2m_set_map(s2m_handle h, const void* pts, size_t n, size_t stride_bytes)
+{ return set_map_impl(h, pts, n, stride_bytes, false); }
+int s2m_set_map_device(s2m_handle h, const void* d_pts, size_t n, size_t stride_bytes)
+{ return set_map_impl(h, d_pts, n, stride_bytes, true); }
+int s2m_set_scan(s2m_handle h, const void* pts, size_t n, size_t stride_bytes)
+{ return set_scan_impl(h, pts, n, stride_bytes, false); }
+int s2m_set_scan_device(s2m_handle h, const void* d_pts, size_t n, size_t stride_bytes)
+{ return set_scan_impl(h, d_pts, n, stride_bytes, true); }
+
+int s2m_optimize_launch(s2m_handle h, const float pose[6])
+{
+    if (!h || !pose) return S2M_ERR_INVALID_ARG;
+    if (!h->have_scan) return fail(h, S2M_ERR_NO_SCAN, "s2m_set_scan has not been called");
+    S2M_HIP(h, hipSetDevice(h->device));
+    memcpy(h->pending_pose_in, pose, 24);
+    h->opt_pending = true;
+    h->pending_skipped = 0;
+    if (h->n_m == 0) { h->pending_skipped = 1; return S2M_OK; }                    // :1297
+    if ((int)h->n_q <= h->prm.min_feats) { h->pending_skipped = 2; return S2M_OK; } // :1300
+    int rc = upload_ctx(h);
+    if (rc) return rc;
+    if ((rc = push_state(h, pose))) return rc;
+    if ((rc = launch_loop(h))) return rc;
+    S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipMemcpyAsync(h->h_trace, h->trace.p, sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
+    return S2M_OK;
+}
+
+int s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu, s2m_result* out)
+{
+    if (!h || !pose) return S2M_ERR_INVALID_ARG;
+    if (!h->opt_pending) return fail(h, S2M_ERR_INVALID_ARG, "no optimize launch pending");
+    h->opt_pending = false;
+    s2m_result r;
+    memset(&r, 0, sizeof(r));
+    r.skipped = h->pending_skipped;
+    h->last_trace_n = 0;
+    float t[6];
+    memcpy(t, h->pending_pose_in, 24);
+    if (!r.skipped) {
+        S2M_HIP(h, hipSetDevice(h->device));
+        S2M_HIP(h, hipStreamSynchronize(h->stream));
+        S2M_HIP(h, hipEventElapsedTime(&h->t_optimize_ms, h->ev_a, h->ev_b));
+        const DevState& s = h->h_state[1];
+        memcpy(t, s.pose, 24);
+        r.iters_run = s.iters_run; r.converged = s.converged; r.is_degenerate = s.isDegenerate;
+        r.n_sel_last = s.n_sel_last;
+        h->persist_degenerate = s.isDegenerate;
+        memcpy(h->persist_matP, s.matP, sizeof(s.matP));
+        // trace: executed iterations; a stalled loop repeats its single no-op record
+        int n_exec = s.iters_run;
+        for (int i = 0; i < n_exec && i < kMaxIter; i++) {
+            if (s.stalled && i > 0) h->last_trace[i] = h->last_trace[0];
+            else h->last_trace[i] = h->h_trace[i];
+        }
+        h->last_trace_n = n_exec < kMaxIter ? n_exec : kMaxIter;
+        host_transform_update(h->prm, imu, t, r.affine);                           // :1317
+    } else {
+        host_pose_to_transform(t, r.affine, nullptr);
+        r.is_degenerate = h->persist_degenerate;
+    }
+    memcpy(r.pose, t, 24);
+    memcpy(pose, t, 24);
+    if (out) *out = r;
+    return S2M_OK;
+}
+
+int s2m_optimize_resident(s2m_handle h, float pose[6], const s2m_imu_init* imu, s2m_result* out)
+{
+    int rc = s2m_optimize_launch(h, pose);
+    if (rc) return rc;
+    return s2m_optimize_collect(h, pose, imu, out);
+}
+
+int s2m_optimize(s2m_handle h, const void* scan, size_t n, size_t stride_bytes, float pose[6],
+                 const s2m_imu_init* imu, s2m_result* out)
+{
+    int rc = s2m_set_scan(h, scan, n, stride_bytes);
+    if (rc) return rc;
+    return s2m_optimize_resident(h, pose, imu, out);
+}
+
+int s2m_get_trace(s2m_handle h, s2m_iter_trace* out, int cap)
+{
+    if (!h || (!out && cap > 0)) return S2M_ERR_INVALID_ARG;
+    int n = h->last_trace_n < cap ? h->last_trace_n : cap;
+    for (int i = 0; i < n; i++) out[i] = h->last_trace[i];
+    return n;
+}
+
+int s2m_surf_optimization(s2m_handle h, const float pose[6], int32_t* idx5, float* d2_5, uint8_t* flag, float* coeff4)
+{
+    if (!h || !pose) return S2M_ERR_INVALID_ARG;
+    if (!h->have_scan) return fail(h, S2M_ERR_NO_SCAN, "s2m_set_scan has not been called");
+    S2M_HIP(h, hipSetDevice(h->device));
+    const size_t n = h->n_q;
+    if (n == 0) return S2M_OK;
+    if (h->n_m == 0) {          // no map: nothing is ever gated
+        if (idx5) for (size_t i = 0; i < 5 * n; i++) idx5[i] = -1;
+        if (d2_5) for (size_t i = 0; i < 5 * n; i++) d2_5[i] = INFINITY;
+        if (flag) memset(flag, 0, n);
+        if (coeff4) memset(coeff4, 0, sizeof(float) * 4 * n);
+        return S2M_OK;
+    }
+    int rc;
+    if ((rc = ensure(h, h->dbg_idx5, sizeof(int32_t) * 5 * n))) return rc;
+    if ((rc = ensure(h, h->dbg_d2, sizeof(float) * 5 * n))) return rc;
+    if ((rc = ensure(h, h->dbg_flag, n))) return rc;
+    if ((rc = ensure(h, h->dbg_coeff, sizeof(float) * 4 * n))) return rc;
+    h->hctx.dbg_idx5 = h->dbg_idx5.as<int32_t>(); h->hctx.dbg_d2 = h->dbg_d2.as<float>();
+    h->hctx.dbg_flag = h->dbg_flag.as<uint8_t>(); h->hctx.dbg_coeff = h->dbg_coeff.as<float>();
+    h->ctx_dirty = true;
+    if ((rc = upload_ctx(h))) return rc;
+    if ((rc = push_state(h, pose))) return rc;
+    hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>());
+    S2M_HIP(h, hipGetLastError());
+    if (idx5) S2M_HIP(h, hipMemcpyAsync(idx5, h->dbg_idx5.p, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, h->stream));
+    if (d2_5) S2M_HIP(h, hipMemcpyAsync(d2_5, h->dbg_d2.p, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, h->stream));
+    if (flag) S2M_HIP(h, hipMemcpyAsync(flag, h->dbg_flag.p, n, hipMemcpyDeviceToHost, h->stream));
+    if (coeff4) S2M_HIP(h, hipMemcpyAsync(coeff4, h->dbg_coeff.p, sizeof(float) * 4 * n, hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    h->hctx.dbg_idx5 = nullptr; h->hctx.dbg_d2 = nullptr; h->hctx.dbg_flag = nullptr; h->hctx.dbg_coeff = nullptr;
+    h->ctx_dirty = true;
+    return upload_ctx(h);
+}
+
+int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6], int32_t* n_sel)
+{
+    if (!h || !pose) return S2M_ERR_INVALID_ARG;
+    if (!h->have_scan) return fail(h, S2M_ERR_NO_SCAN, "s2m_set_scan has not been called");
+    S2M_HIP(h, hipSetDevice(h->device));
+    if (h->n_m == 0 || h->n_q == 0) {
+        if (AtA) memset(AtA, 0, sizeof(float) * 36);
+        if (AtB) memset(AtB, 0, sizeof(float) * 6);
+        if (n_sel) *n_sel = 0;
+        return S2M_OK;
+    }
+    int rc;
+    if ((rc = upload_ctx(h))) return rc;
+    if ((rc = push_state(h, pose))) return rc;
+    const DevCtx* dc = h->dctx.as<DevCtx>();
+    hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, dc, 0, 1);
+    S2M_HIP(h, hipGetLastError());
+    S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    if (AtA) memcpy(AtA, h->h_state[1].AtA, sizeof(float) * 36);
+    if (AtB) memcpy(AtB, h->h_state[1].AtB, sizeof(float) * 6);
+    if (n_sel) *n_sel = h->h_state[1].n_sel_last;
+    return S2M_OK;
+}
+
+int s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float* set_scan_ms)
+{
+    if (!h) return S2M_ERR_INVALID_ARG;
+    if (optimize_ms) *optimize_ms = h->t_optimize_ms;
+    if (set_map_ms) *set_map_ms = h->t_set_map_ms;
+    if (set_scan_ms) *set_scan_ms = h->t_set_scan_ms;
+    return S2M_OK;
+}
+
+int s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float* ms_per_launch)
+{
+    if (!h || !pose || reps < 1 || !ms_per_launch) return S2M_ERR_INVALID_ARG;
+    if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
+    S2M_HIP(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = upload_ctx(h))) return rc;
+    if ((rc = push_state(h, pose))) return rc;
+    const DevCtx* dc = h->dctx.as<DevCtx>();
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
+    S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
+    S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    S2M_HIP(h, hipGetLastError());
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    S2M_HIP(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
+    *ms_per_launch = ms / (float)reps;
+    return S2M_OK;
+}
+
+int s2m_make_scancontext(s2m_handle h, const void* pts, size_t n, size_t stride_bytes,
+                         double desc[S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR], double ringkey[S2M_SC_NUM_RING])
+{
+    int rc = check_records(h, pts, n, stride_bytes);
+    if (rc) return rc;
+    if (!desc || !ringkey) return S2M_ERR_INVALID_ARG;
+    S2M_HIP(h, hipSetDevice(h->device));
+    S2M_HIP(h, hipMemsetAsync(h->sc_bins.p, 0, sizeof(uint32_t) * 1200, h->stream));
+    if (n > 0) {
+        if ((rc = ensure(h, h->raw_scan, n * stride_bytes))) return rc;
+        S2M_HIP(h, hipMemcpyAsync(h->raw_scan.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
+        const int blocks = std::min((int)((n + 255) / 256), 1024);
+        hipLaunchKernelGGL(k_sc_polar_max, dim3(blocks), dim3(256), 0, h->stream,
+                           (const unsigned char*)h->raw_scan.as<unsigned char>(), stride_bytes, (int)n, h->sc_bins.as<uint32_t>());
+    }
+    hipLaunchKernelGGL(k_sc_finish, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)h->sc_bins.as<uint32_t>(),
+                       h->sc_out.as<double>(), h->sc_out.as<double>() + 1200);
+    S2M_HIP(h, hipGetLastError());
+    S2M_HIP(h, hipMemcpyAsync(h->h_sc, h->sc_out.p, sizeof(double) * 1220, hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(desc, h->h_sc, sizeof(double) * 1200);
+    memcpy(ringkey, h->h_sc + 1200, sizeof(double) * 20);
+    return S2M_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,855 @@
+// s2m_kernels.hpp — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the scan-to-map
+// registration path. Compiled with -ffp-contract=off: every fp32 expression that mirrors the
+// reference is evaluated as written (one rounding per operation), and HIP's default
+// correctly-rounded fp32 divide/sqrt keeps the per-correspondence arithmetic bit-identical
+// to an x86-64 (no-FMA) build of the reference.
+//
+// Reference citations are file:line into jimmyshe/liorf (src/mapOptmization.cpp unless named).
+#pragma once
+#include <float.h>
+#include <math.h>
+#include "s2m_types.h"
+
+namespace s2m {
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t f2ord(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ int cell_coord(float v, float o, float inv_e, int n)
+{
+    float f = floorf((v - o) * inv_e);
+    f = fminf(fmaxf(f, 0.0f), (float)(n - 1));      // NaN -> 0, +-inf -> edge cells
+    return (int)f;
+}
+
+__device__ __forceinline__ void swap_if(bool c, float& a, float& b)
+{
+    float t = a; a = c ? b : a; b = c ? t : b;
+}
+__device__ __forceinline__ void swap_if(bool c, int& a, int& b)
+{
+    int t = a; a = c ? b : a; b = c ? t : b;
+}
+
+// ------------------------------------------------------------------------------------------
+// index build: bounding box, cell histogram with per-point rank, exclusive scan, scatter
+// ------------------------------------------------------------------------------------------
+// mm[0..2] = ordered-uint min x,y,z ; mm[3..5] = ordered-uint max x,y,z (host initialises)
+__global__ void k_bbox(const unsigned char* __restrict__ pts, size_t stride, int n, uint32_t* mm)
+{
+    float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float v = p[d];
+            if (isfinite(v)) { mn[d] = fminf(mn[d], v); mx[d] = fmaxf(mx[d], v); }
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[d] = fminf(mn[d], __shfl_down(mn[d], off, 64));
+            mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            atomicMin(&mm[d], f2ord(mn[d]));
+            atomicMax(&mm[3 + d], f2ord(mx[d]));
+        }
+    }
+}
+
+// linear cell id: x-fastest rows (map grid: a query's 3 x-neighbours are one contiguous run)
+__device__ __forceinline__ int lin_rows(const GridDesc& g, int cx, int cy, int cz)
+{
+    return (cz * g.ny + cy) * g.nx + cx;
+}
+// linear cell id: 4x4x4 tile-major (scan grid: 64 consecutive ids are one compact block;
+// requires nx,ny,nz to be multiples of 4)
+__device__ __forceinline__ int lin_tiles(const GridDesc& g, int cx, int cy, int cz)
+{
+    int tx = cx >> 2, ty = cy >> 2, tz = cz >> 2;
+    int tile = (tz * (g.ny >> 2) + ty) * (g.nx >> 2) + tx;
+    return (tile << 6) | ((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3);
+}
+
+template <bool TILED>
+__global__ void k_bin_count(const unsigned char* __restrict__ pts, size_t stride, int n, GridDesc g,
+                            int32_t* __restrict__ cell_of, int32_t* __restrict__ rank_of,
+                            int32_t* __restrict__ counts)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
+    int cx = cell_coord(p[0], g.ox, g.inv_e, g.nx);
+    int cy = cell_coord(p[1], g.oy, g.inv_e, g.ny);
+    int cz = cell_coord(p[2], g.oz, g.inv_e, g.nz);
+    int c = TILED ? lin_tiles(g, cx, cy, cz) : lin_rows(g, cx, cy, cz);
+    cell_of[i] = c;
+    rank_of[i] = atomicAdd(&counts[c], 1);
+}
+
+// exclusive scan, 1024 elements per 256-thread workgroup
+__global__ __launch_bounds__(256) void k_scan_local(const int32_t* __restrict__ in, int32_t* __restrict__ out,
+                                                    int32_t* __restrict__ block_sums, int n)
+{
+    __shared__ int32_t wsum[4];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    int32_t v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (base + k < n) ? in[base + k] : 0;
+    int32_t t = v[0] + v[1] + v[2] + v[3];
+    int32_t incl = t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) if (w < wave) woff += wsum[w];
+    int32_t excl = woff + incl - t;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (base + k < n) out[base + k] = excl; excl += v[k]; }
+    if (threadIdx.x == 255) block_sums[blockIdx.x] = woff + incl;
+}
+
+// in-place exclusive scan of the block sums by one workgroup (any nb)
+__global__ __launch_bounds__(1024) void k_scan_sums(int32_t* __restrict__ sums, int nb)
+{
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < nb; base += 1024) {
+        int i = base + threadIdx.x;
+        int32_t t = (i < nb) ? sums[i] : 0;
+        int32_t incl = t;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            int32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int32_t woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        int32_t carry = carry_s;
+        if (i < nb) sums[i] = carry + woff + incl - t;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(int32_t* __restrict__ out, const int32_t* __restrict__ block_sums,
+                                                  int n, int total)
+{
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
+    const int32_t off = block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (base + k < n) out[base + k] += off;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total;
+}
+
+__global__ void k_scatter_map(const unsigned char* __restrict__ pts, size_t stride, int n,
+                              const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
+                              const int32_t* __restrict__ cell_start, float4* __restrict__ map_sorted)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
+    int pos = cell_start[cell_of[i]] + rank_of[i];
+    map_sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
+}
+
+__global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t stride, int n,
+                               const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
+                               const int32_t* __restrict__ cell_start,
+                               float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz,
+                               int32_t* __restrict__ qperm)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
+    int pos = cell_start[cell_of[i]] + rank_of[i];
+    qx[pos] = p[0]; qy[pos] = p[1]; qz[pos] = p[2]; qperm[pos] = i;
+}
+
+// ------------------------------------------------------------------------------------------
+// per-correspondence arithmetic
+// ------------------------------------------------------------------------------------------
+// 5x3 least-squares plane  A x = -1  by column-pivoted Householder QR in fp32: the
+// algorithm behind `matA0.colPivHouseholderQr().solve(matB0)` (:1104, Eigen 3.3), with every
+// index resolved at compile time so the 5x3 matrix lives in registers.
+__device__ __forceinline__ void plane_fit_5x3(float (&qr)[5][3], float (&x)[3])
+{
+    float hC[3], nU[3], nD[3];
+    int perm[3] = { 0, 1, 2 };
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float s = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 5; i++) s += qr[i][k] * qr[i][k];
+        nD[k] = sqrtf(s); nU[k] = nD[k];
+    }
+    float maxn = nU[0];
+    if (nU[1] > maxn) maxn = nU[1];
+    if (nU[2] > maxn) maxn = nU[2];
+    const float th = maxn * FLT_EPSILON;
+    const float threshold_helper = (th * th) / 5.0f;
+    const float norm_downdate_threshold = sqrtf(FLT_EPSILON);
+    int np = 3;
+
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        int big = k; float bign = nU[k];
+#pragma unroll
+        for (int j = k + 1; j < 3; j++) if (nU[j] > bign) { bign = nU[j]; big = j; }
+        const float big_sq = bign * bign;
+        if (np == 3 && big_sq < threshold_helper * (float)(5 - k)) np = k;
+#pragma unroll
+        for (int j = k + 1; j < 3; j++) {
+            const bool c = (big == j);
+#pragma unroll
+            for (int i = 0; i < 5; i++) swap_if(c, qr[i][k], qr[i][j]);
+            swap_if(c, nU[k], nU[j]); swap_if(c, nD[k], nD[j]); swap_if(c, perm[k], perm[j]);
+        }
+        float tailSq = 0.0f;
+#pragma unroll
+        for (int i = k + 1; i < 5; i++) tailSq += qr[i][k] * qr[i][k];
+        const float c0 = qr[k][k];
+        float beta, tau;
+        if (tailSq <= FLT_MIN) {
+            tau = 0.0f; beta = c0;
+#pragma unroll
+            for (int i = k + 1; i < 5; i++) qr[i][k] = 0.0f;
+        } else {
+            beta = sqrtf(c0 * c0 + tailSq);
+            if (c0 >= 0.0f) beta = -beta;
+            const float den = c0 - beta;
+#pragma unroll
+            for (int i = k + 1; i < 5; i++) qr[i][k] = qr[i][k] / den;
+            tau = (beta - c0) / beta;
+        }
+        qr[k][k] = beta; hC[k] = tau;
+        if (tau != 0.0f) {
+#pragma unroll
+            for (int j = k + 1; j < 3; j++) {
+                float tmp = 0.0f;
+#pragma unroll
+                for (int i = k + 1; i < 5; i++) tmp += qr[i][k] * qr[i][j];
+                tmp += qr[k][j];
+                qr[k][j] -= tau * tmp;
+#pragma unroll
+                for (int i = k + 1; i < 5; i++) qr[i][j] -= (tau * qr[i][k]) * tmp;
+            }
+        }
+#pragma unroll
+        for (int j = k + 1; j < 3; j++) {
+            if (nU[j] != 0.0f) {
+                float temp = fabsf(qr[k][j]) / nU[j];
+                temp = (1.0f + temp) * (1.0f - temp);
+                temp = temp < 0.0f ? 0.0f : temp;
+                const float r = nU[j] / nD[j];
+                const float temp2 = temp * (r * r);
+                if (temp2 <= norm_downdate_threshold) {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int i = k + 1; i < 5; i++) s += qr[i][j] * qr[i][j];
+                    nD[j] = sqrtf(s); nU[j] = nD[j];
+                } else {
+                    nU[j] *= sqrtf(temp);
+                }
+            }
+        }
+    }
+
+    x[0] = x[1] = x[2] = 0.0f;
+    if (np == 0) return;
+    float c[5] = { -1.0f, -1.0f, -1.0f, -1.0f, -1.0f };              // matB0.fill(-1) (:1094)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (k < np) {
+            const float tau = hC[k];
+            if (tau != 0.0f) {
+                float tmp = 0.0f;
+#pragma unroll
+                for (int i = k + 1; i < 5; i++) tmp += qr[i][k] * c[i];
+                tmp += c[k];
+                c[k] -= tau * tmp;
+#pragma unroll
+                for (int i = k + 1; i < 5; i++) c[i] -= (tau * qr[i][k]) * tmp;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 2; i >= 0; i--) {
+        if (i < np) {
+            if (c[i] != 0.0f) {
+                c[i] /= qr[i][i];
+#pragma unroll
+                for (int r = 0; r < i; r++) c[r] -= c[i] * qr[r][i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (i < np) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) if (perm[i] == t) x[t] = c[i];
+        }
+    }
+}
+
+// one row of matA / matB (:1216-1234); sc = srx,crx,sry,cry,srz,crz (:1170-1175)
+__device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, float py, float pz,
+                                             const float (&cf)[4], float (&row)[6], float& rhs)
+{
+    const float srx = sc[0], crx = sc[1], sry = sc[2], cry = sc[3], srz = sc[4], crz = sc[5];
+    const float arx = (-srx * cry * px - (srx * sry * srz + crx * crz) * py + (crx * srz - srx * sry * crz) * pz) * cf[0]
+                    + (crx * cry * px - (srx * crz - crx * sry * srz) * py + (crx * sry * crz + srx * srz) * pz) * cf[1];
+    const float ary = (-crx * sry * px + crx * cry * srz * py + crx * cry * crz * pz) * cf[0]
+                    + (-srx * sry * px + srx * sry * srz * py + srx * cry * crz * pz) * cf[1]
+                    + (-cry * px - sry * srz * py - sry * crz * pz) * cf[2];
+    const float arz = ((crx * sry * crz + srx * srz) * py + (srx * crz - crx * sry * srz) * pz) * cf[0]
+                    + ((-crx * srz + srx * sry * crz) * py + (-srx * sry * srz - crx * crz) * pz) * cf[1]
+                    + (cry * crz * py - cry * srz * pz) * cf[2];
+    row[0] = arz; row[1] = ary; row[2] = arx; row[3] = cf[0]; row[4] = cf[1]; row[5] = cf[2];
+    rhs = -cf[3];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_register: one launch = one surfOptimization() pass (:1074-1143) fused with the matA/matB
+// row assembly of LMOptimization() (:1191-1235) and the first stage of the AtA / AtB
+// reduction (:1237-1239).  One lane = one scan point:
+//   p_sel = T p_ori  ->  exact 5-NN over the 3x3x3 cell neighbourhood (9 contiguous x-runs of
+//   the cell-sorted map)  ->  gate  ->  LS plane  ->  inlier test  ->  weight  ->  Jacobian row
+//   ->  21+6+1 fp64 sums per lane  ->  wave shuffle + LDS reduction  ->  one partial per workgroup.
+// combineOptimizationCoeffs() (:1145-1156) has no counterpart: rejected lanes contribute zeros.
+// ------------------------------------------------------------------------------------------
+struct Top5 {
+    uint64_t key[5];    // (fp32 d2 bits << 32) | original map index: one u64 compare orders (d2, idx)
+    int32_t  pos[5];    // position in the cell-sorted map (to re-read the coordinates)
+};
+
+__device__ __forceinline__ void top5_insert(Top5& t, uint64_t key, int32_t pos)
+{
+    t.key[4] = key; t.pos[4] = pos;
+#pragma unroll
+    for (int j = 4; j > 0; --j) {
+        const bool c = t.key[j] < t.key[j - 1];
+        const uint64_t ka = t.key[j - 1], kb = t.key[j];
+        t.key[j - 1] = c ? kb : ka; t.key[j] = c ? ka : kb;
+        swap_if(c, t.pos[j - 1], t.pos[j]);
+    }
+}
+
+template <bool HOOK>
+__global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ cp)
+{
+    const DevState* __restrict__ st = cp->state;
+    if (!HOOK && st->done) return;
+
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * kBlock + tid;
+    const int nq = cp->n_q;
+
+    double acc[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+
+    if (i < nq) {
+        const GridDesc g = cp->g;
+        const float4* __restrict__ map = cp->map_sorted;
+        const int32_t* __restrict__ cell_start = cp->cell_start;
+
+        const float px = cp->qx[i], py = cp->qy[i], pz = cp->qz[i];               // pointOri (:1085)
+        // pointAssociateToMap (:302-308), association order of the reference expression
+        const float sx = ((st->T[0] * px + st->T[1] * py) + st->T[2]  * pz) + st->T[3];
+        const float sy = ((st->T[4] * px + st->T[5] * py) + st->T[6]  * pz) + st->T[7];
+        const float sz = ((st->T[8] * px + st->T[9] * py) + st->T[10] * pz) + st->T[11];
+
+        const int cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
+        const int cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
+        const int cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+
+        Top5 best;
+#pragma unroll
+        for (int k = 0; k < 5; k++) { best.key[k] = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu; best.pos[k] = 0; }
+
+        for (int dzc = -1; dzc <= 1; dzc++) {
+            const int zz = cz + dzc;
+            if (zz < 0 || zz >= g.nz) continue;
+            for (int dyc = -1; dyc <= 1; dyc++) {
+                const int yy = cy + dyc;
+                if (yy < 0 || yy >= g.ny) continue;
+                const int rowbase = (zz * g.ny + yy) * g.nx;
+                const int s = cell_start[rowbase + x0];
+                const int e = cell_start[rowbase + x1 + 1];
+                for (int j = s; j < e; j++) {
+                    const float4 m = map[j];
+                    const float dx = sx - m.x, dy = sy - m.y, dz = sz - m.z;
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;                 // L2_Simple order
+                    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(m.w);
+                    if (key < best.key[4]) top5_insert(best, key, j);
+                }
+            }
+        }
+
+        const float d2_4 = __uint_as_float((uint32_t)(best.key[4] >> 32));
+        const bool gated = (double)d2_4 < cp->gate_sq;                              // :1097
+        bool keep = false;
+        float cf[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        if (gated) {
+            float qr[5][3];
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const float4 m = map[best.pos[j]];
+                qr[j][0] = m.x; qr[j][1] = m.y; qr[j][2] = m.z;                      // :1099-1101
+            }
+            float nb[5][3];
+#pragma unroll
+            for (int j = 0; j < 5; j++) { nb[j][0] = qr[j][0]; nb[j][1] = qr[j][1]; nb[j][2] = qr[j][2]; }
+            float X[3];
+            plane_fit_5x3(qr, X);                                                    // :1104
+            float pa = X[0], pb = X[1], pc = X[2], pd = 1.0f;
+            const float ps = sqrtf(pa * pa + pb * pb + pc * pc);                      // :1111
+            pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+            bool planeValid = true;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {                                            // :1115-1122
+                const float r = pa * nb[j][0] + pb * nb[j][1] + pc * nb[j][2] + pd;
+                if ((double)fabsf(r) > cp->plane_tol) planeValid = false;
+            }
+            if (planeValid) {
+                const float pd2 = pa * sx + pb * sy + pc * sz + pd;                   // :1125
+                const float rr = sqrtf(sqrtf(px * px + py * py + pz * pz));
+                const float sw = (float)(1.0 - cp->weight_scale * (double)fabsf(pd2) / (double)rr);   // :1127
+                if ((double)sw > cp->weight_min) {                                    // :1135
+                    cf[0] = sw * pa; cf[1] = sw * pb; cf[2] = sw * pc; cf[3] = sw * pd2;              // :1130-1133
+                    keep = true;
+                }
+            }
+        }
+
+        if (keep) {
+            const float sc[6] = { st->sc[0], st->sc[1], st->sc[2], st->sc[3], st->sc[4], st->sc[5] };
+            float row[6], rhs;
+            jacobian_row(sc, px, py, pz, cf, row, rhs);
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int b = a; b < 6; b++) acc[k++] = (double)row[a] * (double)row[b];
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] = (double)row[a] * (double)rhs;
+            acc[27] = 1.0;
+        }
+
+        if (HOOK) {
+            const int o = cp->qperm[i];
+            if (cp->dbg_idx5) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) cp->dbg_idx5[5 * (size_t)o + j] = gated ? (int32_t)(uint32_t)(best.key[j] & 0xffffffffu) : -1;
+            }
+            if (cp->dbg_d2) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) cp->dbg_d2[5 * (size_t)o + j] = __uint_as_float((uint32_t)(best.key[j] >> 32));
+            }
+            if (cp->dbg_flag) cp->dbg_flag[o] = keep ? 1 : 0;
+            if (cp->dbg_coeff) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) cp->dbg_coeff[4 * (size_t)o + j] = cf[j];
+            }
+        }
+    }
+
+    // ---- workgroup reduction: wave shuffle tree, then the 4 waves through LDS in fixed order
+    __shared__ double red[kBlock / 64][kAcc];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < kAcc; k++) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < kAcc) {
+        const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        cp->partials[(size_t)blockIdx.x * kAcc + tid] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 6x6 algebra of LMOptimization (:1237-1271) for one lane
+// ------------------------------------------------------------------------------------------
+// cv::solve(matAtA, matAtB, matX, DECOMP_QR) (:1240): un-pivoted Householder QR in fp32 with
+// unit-length reflectors, rhs transformed, back substitution (OpenCV >= 3.3 hal::QR32f).
+__device__ bool solve6_qr(const float (&Ain)[36], const float (&bin)[6], float (&x)[6])
+{
+    float A[6][6], b[6], hf[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        b[i] = bin[i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) A[i][j] = Ain[i * 6 + j];
+    }
+#pragma unroll
+    for (int l = 0; l < 6; l++) {
+        float vl[6];
+        float nrm = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 6 - l; i++) { vl[i] = A[l + i][l]; nrm += vl[i] * vl[i]; }
+        const float tmpV = vl[0];
+        vl[0] = vl[0] + (vl[0] >= 0.0f ? 1.0f : -1.0f) * sqrtf(nrm);
+        nrm = sqrtf(nrm + vl[0] * vl[0] - tmpV * tmpV);
+#pragma unroll
+        for (int i = 0; i < 6 - l; i++) vl[i] /= nrm;
+#pragma unroll
+        for (int j = l; j < 6; j++) {
+            float v = 0.0f;
+#pragma unroll
+            for (int i = l; i < 6; i++) v += vl[i - l] * A[i][j];
+#pragma unroll
+            for (int i = l; i < 6; i++) A[i][j] -= 2.0f * vl[i - l] * v;
+        }
+        hf[l] = vl[0] * vl[0];
+#pragma unroll
+        for (int i = 1; i < 6 - l; i++) A[l + i][l] = vl[i] / vl[0];
+    }
+#pragma unroll
+    for (int l = 0; l < 6; l++) {
+        float vl[6];
+        vl[0] = 1.0f;
+#pragma unroll
+        for (int j = 1; j < 6 - l; j++) vl[j] = A[j + l][l];
+        float v = 0.0f;
+#pragma unroll
+        for (int i = l; i < 6; i++) v += vl[i - l] * b[i];
+#pragma unroll
+        for (int i = l; i < 6; i++) b[i] -= 2.0f * vl[i - l] * v * hf[l];
+    }
+    bool ok = true;
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+#pragma unroll
+        for (int j = 5; j > i; j--) b[i] -= b[j] * A[i][j];
+        if (fabsf(A[i][i]) < FLT_EPSILON * 10.0f) ok = false;
+        b[i] /= A[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = ok ? b[i] : 0.0f;
+    return ok;
+}
+
+// cv::eigen (:1248): max-pivot Jacobi in fp32, eigenvalues descending, eigenvectors as rows.
+// A and V are LDS scratch of the calling lane (data-dependent indexing).
+__device__ void eigen6_sym(float (*A)[6], float (*V)[6], float* W, int* indR, int* indC)
+{
+    constexpr int N = 6;
+    const float eps = FLT_EPSILON;
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) V[i][j] = (i == j) ? 1.0f : 0.0f;
+    for (int k = 0; k < N; k++) {
+        W[k] = A[k][k];
+        if (k < N - 1) {
+            int m = k + 1; float mv = fabsf(A[k][m]);
+            for (int i = k + 2; i < N; i++) { float v = fabsf(A[k][i]); if (mv < v) { mv = v; m = i; } }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            int m = 0; float mv = fabsf(A[0][k]);
+            for (int i = 1; i < k; i++) { float v = fabsf(A[i][k]); if (mv < v) { mv = v; m = i; } }
+            indC[k] = m;
+        }
+    }
+    for (int it = 0; it < N * N * 30; it++) {
+        int k = 0, l; float mv = fabsf(A[0][indR[0]]);
+        for (int i = 1; i < N - 1; i++) { float v = fabsf(A[i][indR[i]]); if (mv < v) { mv = v; k = i; } }
+        l = indR[k];
+        for (int i = 1; i < N; i++) { float v = fabsf(A[indC[i]][i]); if (mv < v) { mv = v; k = indC[i]; l = i; } }
+        const float p = A[k][l];
+        if (fabsf(p) <= eps) break;
+        const float y = (W[l] - W[k]) * 0.5f;
+        float t = fabsf(y) + hypotf(p, y);
+        float s = hypotf(p, t);
+        const float c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0.0f) { s = -s; t = -t; }
+        A[k][l] = 0.0f;
+        W[k] -= t; W[l] += t;
+#define S2M_ROT(v0, v1) do { const float a0 = (v0), b0 = (v1); (v0) = a0 * c - b0 * s; (v1) = a0 * s + b0 * c; } while (0)
+        for (int i = 0; i < k; i++)     S2M_ROT(A[i][k], A[i][l]);
+        for (int i = k + 1; i < l; i++) S2M_ROT(A[k][i], A[i][l]);
+        for (int i = l + 1; i < N; i++) S2M_ROT(A[k][i], A[l][i]);
+        for (int i = 0; i < N; i++)     S2M_ROT(V[k][i], V[l][i]);
+#undef S2M_ROT
+        for (int j = 0; j < 2; j++) {
+            const int idx = j == 0 ? k : l;
+            if (idx < N - 1) {
+                int m = idx + 1; float mv2 = fabsf(A[idx][m]);
+                for (int i = idx + 2; i < N; i++) { float v = fabsf(A[idx][i]); if (mv2 < v) { mv2 = v; m = i; } }
+                indR[idx] = m;
+            }
+            if (idx > 0) {
+                int m = 0; float mv2 = fabsf(A[0][idx]);
+                for (int i = 1; i < idx; i++) { float v = fabsf(A[i][idx]); if (mv2 < v) { mv2 = v; m = i; } }
+                indC[idx] = m;
+            }
+        }
+    }
+    for (int k = 0; k < N - 1; k++) {
+        int m = k;
+        for (int i = k + 1; i < N; i++) if (W[m] < W[i]) m = i;
+        if (k != m) {
+            float tw = W[m]; W[m] = W[k]; W[k] = tw;
+            for (int i = 0; i < N; i++) { float tv = V[m][i]; V[m][i] = V[k][i]; V[k][i] = tv; }
+        }
+    }
+}
+
+// cv::Mat::inv() (:1263): LU with partial pivoting applied to [A | I], fp32. A is destroyed.
+__device__ bool inv6_lu(float (*A)[6], float (*B)[6])
+{
+    constexpr int N = 6;
+    const float eps = FLT_EPSILON * 10.0f;
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) B[i][j] = (i == j) ? 1.0f : 0.0f;
+    for (int i = 0; i < N; i++) {
+        int k = i;
+        for (int j = i + 1; j < N; j++) if (fabsf(A[j][i]) > fabsf(A[k][i])) k = j;
+        if (fabsf(A[k][i]) < eps) {
+            for (int a = 0; a < N; a++) for (int b = 0; b < N; b++) B[a][b] = 0.0f;
+            return false;
+        }
+        if (k != i) {
+            for (int j = i; j < N; j++) { float t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t; }
+            for (int j = 0; j < N; j++) { float t = B[i][j]; B[i][j] = B[k][j]; B[k][j] = t; }
+        }
+        const float d = -1.0f / A[i][i];
+        for (int j = i + 1; j < N; j++) {
+            const float alpha = A[j][i] * d;
+            for (int m = i + 1; m < N; m++) A[j][m] += alpha * A[i][m];
+            for (int m = 0; m < N; m++) B[j][m] += alpha * B[i][m];
+        }
+    }
+    for (int i = N - 1; i >= 0; i--)
+        for (int j = 0; j < N; j++) {
+            float s = B[i][j];
+            for (int k = i + 1; k < N; k++) s -= A[i][k] * B[k][j];
+            B[i][j] = s / A[i][i];
+        }
+    return true;
+}
+
+// pcl::getTransformation via trans2Affine3f (:348-351) plus the six sin/cos of :1170-1175.
+// sin/cos are evaluated in fp64 and rounded once to fp32 (device sinf/cosf are a few ulp off
+// libm's; the double-rounded value agrees with a correctly rounded fp32 libm result).
+__device__ void pose_to_transform(const float (&t)[6], float* T, float* sc)
+{
+    const float A = (float)cos((double)t[2]), B = (float)sin((double)t[2]);
+    const float C = (float)cos((double)t[1]), D = (float)sin((double)t[1]);
+    const float E = (float)cos((double)t[0]), F = (float)sin((double)t[0]);
+    const float DE = D * E, DF = D * F;
+    T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = t[3];
+    T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = t[4];
+    T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = t[5];
+    sc[0] = B; sc[1] = A; sc[2] = D; sc[3] = C; sc[4] = F; sc[5] = E;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize: second stage of the AtA/AtB reduction (fixed order: bitwise reproducible for a
+// given workgroup partition) and, by lane 0, the rest of LMOptimization (:1177-1292): the
+// 6x6 solve, the iteration-0 degeneracy analysis, the pose update and the convergence test.
+// It leaves the next iteration's transform in DevState, so the 30-iteration loop (:1304-1315)
+// never returns to the host.  mode 1 = normal equations only (observation hook).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(const DevCtx* __restrict__ cp, int iter, int mode)
+{
+    DevState* st = cp->state;
+    if (mode == 0 && st->done) return;
+
+    __shared__ double part[8][32];
+    __shared__ double tot[32];
+    __shared__ float eA[6][6], eV[6][6], eVi[6][6], eV2[6][6], eW[6];
+    __shared__ int eR[6], eC[6];
+
+    const int t = threadIdx.x, col = t & 31, grp = t >> 5;
+    double s = 0.0;
+    if (col < kAcc) {
+        const double* __restrict__ P = cp->partials;
+        const int nb = cp->nblocks;
+        for (int b = grp; b < nb; b += 8) s += P[(size_t)b * kAcc + col];
+    }
+    part[grp][col] = s;
+    __syncthreads();
+    if (t < kAcc) {
+        double v = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < 8; g2++) v += part[g2][t];
+        tot[t] = v;
+    }
+    __syncthreads();
+    if (t != 0) return;
+
+    const int n_sel = (int)tot[27];
+    float AtA[36], AtB[6];
+    {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) { const float v = (float)tot[k++]; AtA[a * 6 + b] = v; AtA[b * 6 + a] = v; }
+#pragma unroll
+        for (int a = 0; a < 6; a++) AtB[a] = (float)tot[21 + a];
+    }
+#pragma unroll
+    for (int k = 0; k < 36; k++) st->AtA[k] = AtA[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) st->AtB[k] = AtB[k];
+    st->n_sel_last = n_sel;
+    if (mode == 1) return;
+
+    s2m_iter_trace tr;
+    tr.n_sel = n_sel; tr.stepped = 0; tr.deltaR = 0.0f; tr.deltaT = 0.0f;
+    float pose[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) { pose[k] = st->pose[k]; tr.pose[k] = pose[k]; tr.delta[k] = 0.0f; }
+
+    if (n_sel < cp->min_corr) {                         // :1178-1180: false, pose unchanged;
+        st->stalled = 1; st->done = 1;                  // the remaining iterations repeat this no-op
+        st->iters_run = cp->max_iter;
+        cp->trace[iter] = tr;
+        return;
+    }
+
+    float X[6];
+    solve6_qr(AtA, AtB, X);                             // :1240
+
+    if (iter == 0) {                                    // :1242-1264
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eA[i][j] = AtA[i * 6 + j];
+        eigen6_sym(eA, eV, eW, eR, eC);
+        int degenerate = 0;
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eV2[i][j] = eV[i][j];
+        for (int i = 5; i >= 0; i--) {
+            if (eW[i] < cp->eig_thresh) { for (int j = 0; j < 6; j++) eV2[i][j] = 0.0f; degenerate = 1; }
+            else break;
+        }
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eA[i][j] = eV[i][j];
+        inv6_lu(eA, eVi);
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {          // matP = matV.inv() * matV2
+            double a = 0.0;
+            for (int k = 0; k < 6; k++) a += (double)eVi[i][k] * (double)eV2[k][j];
+            st->matP[i * 6 + j] = (float)a;
+        }
+        st->isDegenerate = degenerate;
+    }
+    if (st->isDegenerate) {                             // :1266-1271
+        float X2[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) X2[k] = X[k];
+        for (int i = 0; i < 6; i++) {
+            double a = 0.0;
+            for (int k = 0; k < 6; k++) a += (double)st->matP[i * 6 + k] * (double)X2[k];
+            X[i] = (float)a;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose[k] += X[k];        // :1273-1278
+
+    const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
+    const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);               // :1280-1283
+    const double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
+    const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);               // :1284-1287
+    const bool conv = ((double)deltaR < cp->conv_deg) && ((double)deltaT < cp->conv_cm);   // :1289
+
+    tr.stepped = 1; tr.deltaR = deltaR; tr.deltaT = deltaT;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; st->pose[k] = pose[k]; }
+    cp->trace[iter] = tr;
+
+    float T[12], sc[6];
+    pose_to_transform(pose, T, sc);
+#pragma unroll
+    for (int k = 0; k < 12; k++) st->T[k] = T[k];
+#pragma unroll
+    for (int k = 0; k < 6; k++) st->sc[k] = sc[k];
+    st->iters_run = iter + 1;
+    if (conv && !st->converged) st->converged = 1;
+    if (conv && cp->early_exit) st->done = 1;           // break (:1313-1314)
+}
+
+// ------------------------------------------------------------------------------------------
+// ScanContext descriptor (include/Scancontext.cpp:151-211): max-z polar histogram, 20 rings x
+// 60 sectors, LDS bins per workgroup merged with global atomicMax on an order-preserving
+// integer image of fp32 z; ring key = row mean.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sc_polar_max(const unsigned char* __restrict__ pts, size_t stride, int n,
+                                                      uint32_t* __restrict__ bins /*[1200], 0 = empty*/)
+{
+    __shared__ uint32_t lb[S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR];
+    for (int k = threadIdx.x; k < S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR; k += blockDim.x) lb[k] = 0u;
+    __syncthreads();
+    const double kdeg = 180.0 / M_PI;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
+        const float x = p[0], y = p[1];
+        const float z = (float)((double)p[2] + 2.0);                       // LIDAR_HEIGHT (:168)
+        const float rng = sqrtf(x * x + y * y);                            // :171
+        float th;                                                          // xy2theta (:23-36)
+        if ((x >= 0) & (y >= 0))      th = (float)(kdeg * (double)atanf(y / x));
+        else if ((x < 0) & (y >= 0))  th = (float)(180.0 - (kdeg * (double)atanf(y / (-x))));
+        else if ((x < 0) & (y < 0))   th = (float)(180.0 + (kdeg * (double)atanf(y / x)));
+        else if ((x >= 0) & (y < 0))  th = (float)(360.0 - (kdeg * (double)atanf((-y) / x)));
+        else th = NAN;
+        if ((double)rng > 80.0) continue;                                  // PC_MAX_RADIUS (:175)
+        if (!(z == z)) continue;                                           // NaN z never wins desc < z
+        const double rv = ceil(((double)rng / 80.0) * 20.0);               // :178
+        const double sv = ceil(((double)th / 360.0) * 60.0);               // :179
+        int ring = (rv != rv) ? 1 : (int)fmin(fmax(rv, 1.0), 20.0);
+        int sect = (sv != sv) ? 1 : (int)fmin(fmax(sv, 1.0), 60.0);
+        atomicMax(&lb[(ring - 1) * S2M_SC_NUM_SECTOR + (sect - 1)], f2ord(z));
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR; k += blockDim.x)
+        if (lb[k]) atomicMax(&bins[k], lb[k]);
+}
+
+__global__ __launch_bounds__(64) void k_sc_finish(const uint32_t* __restrict__ bins, double* __restrict__ desc,
+                                                  double* __restrict__ ringkey)
+{
+    // one wave; lane r < 20 owns ring r
+    const int r = threadIdx.x;
+    if (r >= S2M_SC_NUM_RING) return;
+    double s = 0.0;
+    for (int k = 0; k < S2M_SC_NUM_SECTOR; k++) {
+        const uint32_t u = bins[r * S2M_SC_NUM_SECTOR + k];
+        double v = 0.0;                                                    // NO_POINT -> 0 (:187-190)
+        if (u) {
+            const uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+            const float z = __uint_as_float(b);
+            // desc starts at -1000 and takes z only if -1000 < z (:182); -1000 -> 0 afterwards
+            v = ((double)z > -1000.0) ? (double)z : 0.0;
+        }
+        desc[r * S2M_SC_NUM_SECTOR + k] = v;
+        s += v;
+    }
+    ringkey[r] = s / 60.0;                                                 // row mean (:198-211)
+}
+
+}  // namespace s2m

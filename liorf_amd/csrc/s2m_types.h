@@ -1,0 +1,60 @@
+// s2m_types.h — device/host shared structures of the gfx950 scan-to-map path.
+// Internal to liorf_amd/csrc; the public boundary is include/liorf_s2m.h.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "../../include/liorf_s2m.h"
+
+namespace s2m {
+
+constexpr int kBlock = 256;            // threads per workgroup of the registration kernel (4 waves)
+constexpr int kAcc = 28;               // 21 upper-triangular JtJ + 6 Jtr + 1 correspondence count
+constexpr int kMaxIter = 64;           // trace capacity
+constexpr int kBlocksQuantum = 16;     // graph cache key granularity (workgroups)
+
+// Uniform search grid over the map: cell edge E >= sqrt(gate_sq)*(1+2^-10), so the 3x3x3
+// neighbourhood of a query's cell holds every map point with fp32 d2 < gate_sq.
+struct GridDesc {
+    float ox, oy, oz;     // origin (min corner minus one cell)
+    float inv_e;          // 1 / E
+    int   nx, ny, nz;     // cells per axis
+    int   ncells;
+};
+
+// Per-scan loop state, lives in device memory; written only by the finalize kernel.
+struct DevState {
+    float pose[6];        // transformTobeMapped                (reference :134)
+    float T[12];          // transPointAssociateToMap, row-major (:142)
+    float sc[6];          // srx,crx,sry,cry,srz,crz             (:1170-1175)
+    float matP[36];       // degeneracy projector                (:140)
+    float AtA[36];        // last normal equations (observation hook)
+    float AtB[6];
+    int32_t isDegenerate; // (:139)
+    int32_t done;         // converged (early_exit) or stalled: later launches return at once
+    int32_t converged;
+    int32_t iters_run;
+    int32_t n_sel_last;
+    int32_t stalled;      // n_sel < min_corr: every further iteration is the same no-op
+};
+
+// Everything a kernel needs, in device memory so a captured graph stays valid when
+// buffers grow or the grid changes; kernels receive only a pointer to this.
+struct DevCtx {
+    GridDesc g;
+    const float4* map_sorted;     // [n_m] x,y,z, original index (bit pattern), cell-sorted
+    const int32_t* cell_start;    // [ncells+1]
+    const float* qx; const float* qy; const float* qz;   // [n_q] lidar-frame scan, SoA, locality-sorted
+    const int32_t* qperm;         // [n_q] sorted position -> original scan index
+    int32_t n_q, n_m, nblocks;
+    double* partials;             // [nblocks][kAcc]
+    DevState* state;
+    s2m_iter_trace* trace;        // [kMaxIter]
+    // parameters
+    double gate_sq, plane_tol, weight_scale, weight_min, conv_deg, conv_cm;
+    float  eig_thresh;
+    int32_t min_corr, max_iter, early_exit;
+    // observation outputs of the hook variant (original scan order), may be null
+    int32_t* dbg_idx5; float* dbg_d2; uint8_t* dbg_flag; float* dbg_coeff;
+};
+
+}  // namespace s2m

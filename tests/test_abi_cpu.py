@@ -1,0 +1,70 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, and fails loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from liorf_amd import s2m
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "liorf_s2m.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(s2m_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_and_binding_agree():
+    assert _header_symbols() == sorted(s2m.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(s2m.LIB_PATH)
+    for name in _header_symbols():
+        assert hasattr(lib, name), f"{name} declared in include/liorf_s2m.h but not exported"
+
+
+def test_default_params_are_the_reference_constants():
+    p = s2m.default_params()
+    assert p.struct_size == C.sizeof(s2m.Params)
+    assert (p.k_neighbors, p.min_corr, p.min_feats, p.max_iter) == (5, 50, 30, 30)
+    assert (p.gate_sq, p.plane_tol, p.weight_scale, p.weight_min) == (1.0, 0.2, 0.9, 0.1)
+    assert (p.conv_deg, p.conv_cm, p.eig_thresh) == (0.05, 0.05, 100.0)
+    assert p.early_exit == 1 and p.imu_type == 0
+
+
+def test_version_string():
+    assert b"gfx950" in s2m.load_library().s2m_version()
+
+
+def test_invalid_params_rejected_without_touching_a_gpu():
+    lib = s2m.load_library()
+    p = s2m.default_params()
+    p.struct_size = 4
+    h = C.c_void_p()
+    assert lib.s2m_create(C.byref(p), C.byref(h)) == -1 and not h
+    p = s2m.default_params(k_neighbors=3)
+    assert lib.s2m_create(C.byref(p), C.byref(h)) == -1
+    assert lib.s2m_create(None, None) == -1
+
+
+def test_no_cpu_fallback():
+    """Without a gfx950 device the product refuses to run (it must never fall back to a CPU path)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(s2m.S2MError, match="NO_DEVICE"):
+        s2m.MapOptimizationS2M()
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under liorf_amd/ may import, link or call it."""
+    pat = re.compile(r"from\s+oracle|import\s+oracle|liboracle|s2m_oracle\.h|\borc_[a-zA-Z]|oracle/_ref|nanoflann")
+    for root, _, files in os.walk(os.path.join(ROOT, "liorf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
+                src = open(os.path.join(root, f)).read()
+                assert not pat.search(src), f"{f} reaches into the oracle"

@@ -1,0 +1,193 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+
+Bars (BASELINE.json north_star): kNN indices and distances bit-exact on every gated query,
+plane/weight outputs bit-exact, normal equations within 1e-5 relative, pose delta per LM
+iteration within 1e-4 m / 1e-4 rad.  PARITY UNPINNED: the oracle is a restatement, the
+reference ships no fixtures for this path (oracle/s2m_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from liorf_amd import s2m, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    g = s2m.MapOptimizationS2M()
+    yield g
+    g.close()
+
+
+def _pair(gpu, cfg, **orc_kw):
+    m, s = synth.to_xyzi(cfg["map"]), synth.to_xyzi(cfg["scan"])
+    gpu.setInputCloud(m)
+    gpu.setScan(s)
+    orc = O.Oracle(num_threads=8, **orc_kw)
+    orc.set_map(m)
+    orc.set_scan(s)
+    return orc
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_surf_optimization_bit_exact(gpu, name):
+    cfg = synth.make_config(name)
+    orc = _pair(gpu, cfg, knn_backend=0)
+    for pose in (cfg["pose_init"], cfg["pose_gt"]):
+        idx, d2, flag, coeff = gpu.surfOptimization(pose)
+        oidx, od2, oflag, ocoeff = orc.surfOptimization(pose)
+        gated = oidx[:, 0] >= 0
+        assert gated.sum() > 0.5 * len(gated)
+        assert np.array_equal(idx[:, 0] >= 0, gated), "gate decision differs"
+        assert np.array_equal(idx[gated], oidx[gated])
+        assert np.array_equal(d2[gated].view(np.uint32), od2[gated].view(np.uint32))
+        assert np.array_equal(flag, oflag)
+        assert np.array_equal(coeff.view(np.uint32), ocoeff.view(np.uint32))
+
+
+def test_normal_equations(gpu, cfg_small):
+    orc = _pair(gpu, cfg_small, knn_backend=1)
+    orc.surfOptimization(cfg_small["pose_init"])
+    oAtA, oAtB, on = orc.normal_eq()
+    AtA, AtB, n = gpu.normal_eq(cfg_small["pose_init"])
+    assert n == on
+    assert np.allclose(AtA, oAtA, rtol=1e-5, atol=1e-5 * np.abs(oAtA).max())
+    assert np.allclose(AtB, oAtB, rtol=1e-5, atol=1e-5 * np.abs(oAtB).max())
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_lm_loop_pose_delta_per_iteration(gpu, name):
+    cfg = synth.make_config(name)
+    orc = _pair(gpu, cfg, knn_backend=1)
+    gpu.transformTobeMapped = cfg["pose_init"].copy()
+    r = gpu.scan2MapOptimization()
+    ro = orc.scan2MapOptimization(cfg["pose_init"])
+    assert (r.iters_run, r.converged, r.is_degenerate) == (ro.iters_run, ro.converged, ro.is_degenerate)
+    tg, to = gpu.trace(), orc.trace()
+    assert len(tg) == len(to) == r.iters_run
+    for a, b in zip(tg, to):
+        assert abs(a.n_sel - b.n_sel) <= max(3, int(2e-4 * b.n_sel))      # threshold flips, bounded
+        da, db = np.array(a.delta), np.array(b.delta)
+        assert np.abs(da[:3] - db[:3]).max() <= 1e-4        # rad
+        assert np.abs(da[3:] - db[3:]).max() <= 1e-4        # m
+    assert np.abs(np.array(r.pose) - np.array(ro.pose)).max() <= 1e-4
+    if name == "small":     # and it registers within noise of the ground truth ("tiny" barely constrains x)
+        assert np.abs(np.array(r.pose)[3:] - cfg["pose_gt"][3:]).max() < 0.03
+        assert np.abs(np.array(r.pose)[:3] - cfg["pose_gt"][:3]).max() < 2e-3
+
+
+def test_soft_conditions_are_not_errors(gpu, cfg_tiny):
+    m, s = synth.to_xyzi(cfg_tiny["map"]), synth.to_xyzi(cfg_tiny["scan"])
+    pose = cfg_tiny["pose_init"]
+    # no map (cloudKeyPoses3D empty, reference :1297)
+    gpu.setInputCloud(m[:0])
+    gpu.setScan(s)
+    gpu.transformTobeMapped = pose.copy()
+    r = gpu.scan2MapOptimization()
+    assert r.skipped == 1 and r.iters_run == 0 and np.array_equal(np.array(r.pose, np.float32), pose)
+    # not enough features (reference :1300): exactly 30 is still too few
+    gpu.setInputCloud(m)
+    gpu.setScan(s[:30])
+    gpu.transformTobeMapped = pose.copy()
+    r = gpu.scan2MapOptimization()
+    assert r.skipped == 2 and np.array_equal(np.array(r.pose, np.float32), pose)
+    # fewer than 50 correspondences (reference :1178): 30 iterations, pose unchanged
+    far = s[:200].copy()
+    far[:, :3] += 500.0
+    gpu.setScan(far)
+    gpu.transformTobeMapped = pose.copy()
+    r = gpu.scan2MapOptimization()
+    orc = O.Oracle(knn_backend=1)
+    orc.set_map(m)
+    orc.set_scan(far)
+    ro = orc.scan2MapOptimization(pose)
+    assert (r.skipped, r.iters_run, r.converged, r.n_sel_last) == (0, 30, 0, 0) == (ro.skipped, ro.iters_run, ro.converged, ro.n_sel_last)
+    assert np.array_equal(np.array(r.pose, np.float32), pose)
+    assert len(gpu.trace()) == 30
+
+
+def test_ragged_strides_and_repeat_calls(gpu, cfg_tiny):
+    """stride 12 (packed xyz) and stride 32 (PointXYZI) give identical results; handles are reusable."""
+    m3, s3 = cfg_tiny["map"], cfg_tiny["scan"]
+    gpu.setInputCloud(m3)
+    gpu.setScan(s3)
+    a = gpu.surfOptimization(cfg_tiny["pose_init"])
+    gpu.setInputCloud(synth.to_xyzi(m3))
+    gpu.setScan(synth.to_xyzi(s3))
+    b = gpu.surfOptimization(cfg_tiny["pose_init"])
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_degenerate_scene_ground_only(gpu):
+    """A single plane leaves x, y, yaw unobservable: isDegenerate and the projected step match."""
+    rng = np.random.default_rng(7)
+    n_m, n_q = 20000, 3000
+    m = np.stack([rng.uniform(-30, 30, n_m), rng.uniform(-30, 30, n_m), rng.normal(-1.73, 0.01, n_m)], 1).astype(np.float32)
+    m = synth.voxel_thin(m.astype(np.float64), 0.5).astype(np.float32)
+    q = np.stack([rng.uniform(-20, 20, n_q), rng.uniform(-20, 20, n_q), rng.normal(-1.73, 0.01, n_q)], 1).astype(np.float32)
+    pose = np.array([0.004, -0.003, 0.01, 0.05, -0.04, 0.06], np.float32)
+    gpu.setInputCloud(m)
+    gpu.setScan(q)
+    gpu.transformTobeMapped = pose.copy()
+    r = gpu.scan2MapOptimization()
+    orc = O.Oracle(knn_backend=1)
+    orc.set_map(m)
+    orc.set_scan(q)
+    ro = orc.scan2MapOptimization(pose)
+    assert ro.is_degenerate == 1 and r.is_degenerate == 1
+    assert r.iters_run == ro.iters_run
+    assert np.abs(np.array(r.pose) - np.array(ro.pose)).max() <= 1e-4
+
+
+def test_full_size_properties_kitti64(gpu, cfg_kitti64):
+    """BASELINE configs[1] size: properties that need no oracle pass over 120k x 200k."""
+    cfg = cfg_kitti64
+    m, s = synth.to_xyzi(cfg["map"]), synth.to_xyzi(cfg["scan"])
+    gpu.setInputCloud(m)
+    gpu.setScan(s)
+    idx, d2, flag, coeff = gpu.surfOptimization(cfg["pose_init"])
+    gated = idx[:, 0] >= 0
+    assert gated.mean() > 0.8
+    # sortedness and gate
+    assert np.all(np.diff(d2[gated], axis=1) >= 0) and np.all(d2[gated][:, 4] < 1.0)
+    # the reported distances are the distances to the reported indices (fp32, reference order)
+    from conftest import transform_points
+    T = O.getTransformation(cfg["pose_init"])
+    q = transform_points(T, cfg["scan"])
+    nb = cfg["map"][idx[gated]]                       # (g,5,3)
+    dx = q[gated][:, None, :] - nb
+    dd = (dx[..., 0] * dx[..., 0] + dx[..., 1] * dx[..., 1]) + dx[..., 2] * dx[..., 2]
+    assert np.array_equal(dd.astype(np.float32).view(np.uint32), d2[gated].view(np.uint32))
+    # spot-check exactness against the oracle's brute force on a seeded sample
+    rng = np.random.default_rng(3)
+    for i in rng.choice(np.nonzero(gated)[0], 64, replace=False):
+        oi, od = O.knn5_brute(cfg["map"], q[i])
+        assert np.array_equal(oi, idx[i]) and np.array_equal(od, d2[i])
+    # permutation invariance: shuffling the scan permutes the outputs and leaves AtA unchanged
+    perm = rng.permutation(len(s))
+    AtA, AtB, n = gpu.normal_eq(cfg["pose_init"])
+    gpu.setScan(s[perm])
+    idx2, d22, flag2, coeff2 = gpu.surfOptimization(cfg["pose_init"])
+    assert np.array_equal(idx2, idx[perm]) and np.array_equal(flag2, flag[perm]) and np.array_equal(coeff2, coeff[perm])
+    AtA2, AtB2, n2 = gpu.normal_eq(cfg["pose_init"])
+    assert n2 == n == int(flag.sum())
+    assert np.allclose(AtA2, AtA, rtol=1e-6) and np.allclose(AtB2, AtB, rtol=1e-5, atol=1e-3)
+    # registration converges to the ground truth within noise
+    gpu.transformTobeMapped = cfg["pose_init"].copy()
+    r = gpu.scan2MapOptimization()
+    assert r.converged == 1 and r.iters_run < 30
+    assert np.abs(np.array(r.pose)[3:] - cfg["pose_gt"][3:]).max() < 0.02
+    assert np.abs(np.array(r.pose)[:3] - cfg["pose_gt"][:3]).max() < 1e-3
+
+
+def test_scancontext_descriptor(gpu, cfg_small):
+    desc, key = gpu.makeScancontext(synth.to_xyzi(cfg_small["scan"]))
+    odesc, okey = O.make_scancontext(synth.to_xyzi(cfg_small["scan"]))
+    # device atanf vs libm atanf may differ in the last ulp: a point on a sector boundary can
+    # move to the neighbouring bin; bound the number of differing bins instead of demanding zero
+    assert (desc != odesc).sum() <= 2
+    same = desc == odesc
+    assert np.allclose(key[same.all(axis=1)], okey[same.all(axis=1)], rtol=0, atol=1e-12)
