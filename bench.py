@@ -74,15 +74,23 @@ def main():
     cfg = synth.make_config(args.workload, scan_index=rank)
     n_q, n_m = cfg["scan"].shape[0], cfg["map"].shape[0]
     eng = s2m.MapOptimizationS2M(device_id=local_rank, early_exit=0)
-    eng.setInputCloud(synth.to_xyzi(cfg["map"]))
-    eng.setScan(synth.to_xyzi(cfg["scan"]))
-    tm = eng.timing()
+    # inputs resident in HBM before the timed region: raw PointXYZI records of map and scan
+    d_map = torch.from_numpy(synth.to_xyzi(cfg["map"])).to(dev)
+    d_scan = torch.from_numpy(synth.to_xyzi(cfg["scan"])).to(dev)
+    torch.cuda.synchronize()
+    for _ in range(2):          # second call = steady state (buffers already sized)
+        eng.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
+        eng.setScanDevice(d_scan.data_ptr(), n_q, 32)
+        tm = eng.timing()
     max_iter = eng.params.max_iter
 
     rec = torch.zeros(8, dtype=torch.float32, device=dev)
     gathered = [torch.zeros(8, dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
 
     def step():
+        # one scan2MapOptimization(): scan ordering/SoA prep + 30 x {k_register, k_finalize}; the map
+        # index (the reference's kd-tree build, once per scan) is timed separately, see map_index_build_ms
+        eng.setScanDevice(d_scan.data_ptr(), n_q, 32)
         eng.launch(cfg["pose_init"])
         r = eng.collect()
         if world > 1:      # RCCL all-gather of {pose[6], iters, n_sel} over xGMI

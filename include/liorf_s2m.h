@@ -166,6 +166,11 @@ int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float*
  * between two HIP events on the handle's stream; returns mean ms per launch. */
 int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float* ms_per_launch);
 
+/* Diagnostics: one k_register pass at `pose`; per wave (64 locality-sorted scan points) 8 words:
+ * wall-clock (100 MHz) at start / after the tile search / after plane+Jacobian / at end, then
+ * tile chunks, box rows, staged points, 0. Returns the number of waves written (<= cap_waves). */
+int  s2m_debug_wave_profile(s2m_handle h, const float pose[6], uint64_t* out, size_t cap_waves);
+
 /* ---- ScanContext descriptor (BASELINE config 5) ------------------------- */
 /* SCManager::makeScancontext + makeRingkeyFromScancontext
  * (reference include/Scancontext.cpp:151-211): desc is 20x60 row-major doubles,

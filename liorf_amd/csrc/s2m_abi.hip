@@ -46,7 +46,7 @@ struct s2m_context {
     // scan side
     DevBuf raw_scan, qx, qy, qz, qperm, q_counts, q_cell_start, q_cell_of, q_rank_of;
     // shared
-    DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, sc_bins, sc_out;
+    DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
 
     DevCtx hctx{};
     bool ctx_dirty = true;
@@ -69,6 +69,7 @@ struct s2m_context {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
     float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
     bool opt_pending = false;
+    bool scan_timing_pending = false;
     int pending_skipped = 0;
     float pending_pose_in[6] = { 0 };
     s2m_iter_trace last_trace[kMaxIter];
@@ -106,10 +107,8 @@ int ensure(s2m_context* h, DevBuf& b, size_t bytes)
 int upload_ctx(s2m_context* h)
 {
     if (!h->ctx_dirty) return S2M_OK;
-    *h->h_ctx_pin = h->hctx;
-    S2M_HIP(h, hipMemcpyAsync(h->dctx.p, h->h_ctx_pin, sizeof(DevCtx), hipMemcpyHostToDevice, h->stream));
-    // the pinned mirror may be rewritten by the next call: make the copy complete first
-    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(k_set_ctx, dim3(1), dim3(64), 0, h->stream, h->dctx.as<DevCtx>(), h->hctx);
+    S2M_HIP(h, hipGetLastError());
     h->ctx_dirty = false;
     return S2M_OK;
 }
@@ -205,7 +204,7 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
 
     S2M_HIP(h, hipMemsetAsync(h->m_counts.p, 0, sizeof(int32_t) * ((size_t)g.ncells + 1), h->stream));
     const int nb = ((int)n + 255) / 256;
-    hipLaunchKernelGGL(k_bin_count<false>, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n, g,
+    hipLaunchKernelGGL(k_bin_count, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n, g,
                        h->m_cell_of.as<int32_t>(), h->m_rank_of.as<int32_t>(), h->m_counts.as<int32_t>());
     S2M_HIP(h, hipGetLastError());
     if ((rc = device_exclusive_scan(h, h->m_counts.as<int32_t>(), h->m_cell_start.as<int32_t>(), g.ncells, (int)n))) return rc;
@@ -219,7 +218,8 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
     h->hctx.cell_start = h->m_cell_start.as<int32_t>();
     h->ctx_dirty = true;
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
-    if ((rc = upload_ctx(h))) return rc;            // synchronises: the caller's buffer is free again
+    if ((rc = upload_ctx(h))) return rc;
+    S2M_HIP(h, hipStreamSynchronize(h->stream));     // the caller's buffer is free again
     S2M_HIP(h, hipEventElapsedTime(&h->t_set_map_ms, h->ev_c, h->ev_d));
     return S2M_OK;
 }
@@ -239,7 +239,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     h->ctx_dirty = true;
     if ((rc = ensure(h, h->partials, sizeof(double) * kAcc * (size_t)nblocks))) return rc;
     h->hctx.partials = h->partials.as<double>();
-    if (n == 0) { h->t_set_scan_ms = 0; return upload_ctx(h); }
+    if (n == 0) { h->t_set_scan_ms = 0; h->scan_timing_pending = false; return upload_ctx(h); }
 
     const unsigned char* d_pts;
     if (on_device) d_pts = static_cast<const unsigned char*>(pts);
@@ -248,35 +248,22 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
         S2M_HIP(h, hipMemcpyAsync(h->raw_scan.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
         d_pts = h->raw_scan.as<unsigned char>();
     }
-    float mn[3], mx[3];
-    if ((rc = device_bbox(h, d_pts, stride, (int)n, mn, mx))) return rc;
-
-    // locality grid in the lidar frame (ordering only: any cell size is correct). Cells are
-    // numbered 4x4x4-tile-major so that consecutive lanes hold spatially compact points and a
-    // rigid transform keeps them compact in the map frame.
-    float ext = std::max(std::max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
-    float Es = std::max(1.0f, ext / 500.0f);
-    GridDesc g{};
-    g.inv_e = 1.0f / Es; g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-    auto dim4 = [&](float lo, float hi) { int c = (int)std::floor((hi - lo) * g.inv_e) + 1; return ((c + 3) / 4) * 4; };
-    g.nx = dim4(mn[0], mx[0]); g.ny = dim4(mn[1], mx[1]); g.nz = dim4(mn[2], mx[2]);
-    g.ncells = g.nx * g.ny * g.nz;
-
+    // locality order of the scan: log-polar Z-order bins (k_polar_count), no host round trip
     if ((rc = ensure(h, h->qx, sizeof(float) * n))) return rc;
     if ((rc = ensure(h, h->qy, sizeof(float) * n))) return rc;
     if ((rc = ensure(h, h->qz, sizeof(float) * n))) return rc;
     if ((rc = ensure(h, h->qperm, sizeof(int32_t) * n))) return rc;
-    if ((rc = ensure(h, h->q_counts, sizeof(int32_t) * ((size_t)g.ncells + 1)))) return rc;
-    if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * ((size_t)g.ncells + 1)))) return rc;
+    if ((rc = ensure(h, h->q_counts, sizeof(int32_t) * kPolarCells))) return rc;
+    if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
     if ((rc = ensure(h, h->q_rank_of, sizeof(int32_t) * n))) return rc;
 
-    S2M_HIP(h, hipMemsetAsync(h->q_counts.p, 0, sizeof(int32_t) * ((size_t)g.ncells + 1), h->stream));
+    S2M_HIP(h, hipMemsetAsync(h->q_counts.p, 0, sizeof(int32_t) * kPolarCells, h->stream));
     const int nb = ((int)n + 255) / 256;
-    hipLaunchKernelGGL(k_bin_count<true>, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n, g,
+    hipLaunchKernelGGL(k_polar_count, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
                        h->q_cell_of.as<int32_t>(), h->q_rank_of.as<int32_t>(), h->q_counts.as<int32_t>());
-    S2M_HIP(h, hipGetLastError());
-    if ((rc = device_exclusive_scan(h, h->q_counts.as<int32_t>(), h->q_cell_start.as<int32_t>(), g.ncells, (int)n))) return rc;
+    hipLaunchKernelGGL(k_polar_scan, dim3(1), dim3(1024), 0, h->stream,
+                       (const int32_t*)h->q_counts.as<int32_t>(), h->q_cell_start.as<int32_t>());
     hipLaunchKernelGGL(k_scatter_scan, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
                        (const int32_t*)h->q_cell_of.as<int32_t>(), (const int32_t*)h->q_rank_of.as<int32_t>(),
                        (const int32_t*)h->q_cell_start.as<int32_t>(),
@@ -287,9 +274,8 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     h->hctx.qperm = h->qperm.as<int32_t>();
     h->ctx_dirty = true;
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
-    if ((rc = upload_ctx(h))) return rc;
-    S2M_HIP(h, hipEventElapsedTime(&h->t_set_scan_ms, h->ev_c, h->ev_d));
-    return S2M_OK;
+    h->scan_timing_pending = true;
+    return upload_ctx(h);     // asynchronous; a device-resident source must outlive the next synchronising call
 }
 
 void fill_state(s2m_context* h, DevState* s, const float pose[6])
@@ -303,8 +289,10 @@ void fill_state(s2m_context* h, DevState* s, const float pose[6])
 
 int push_state(s2m_context* h, const float pose[6])
 {
-    fill_state(h, &h->h_state[0], pose);
-    S2M_HIP(h, hipMemcpyAsync(h->state.p, &h->h_state[0], sizeof(DevState), hipMemcpyHostToDevice, h->stream));
+    DevState s;
+    fill_state(h, &s, pose);
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, h->stream, h->state.as<DevState>(), s);
+    S2M_HIP(h, hipGetLastError());
     return S2M_OK;
 }
 
@@ -318,7 +306,7 @@ int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
     S2M_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     for (int it2 = 0; it2 < h->prm.max_iter; it2++) {
         hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, dc, it2, 0);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, it2, 0);
     }
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "hipStreamEndCapture", e);
@@ -348,7 +336,7 @@ int launch_loop(s2m_context* h)
     S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
     for (int it = 0; it < h->prm.max_iter; it++) {
         hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, dc, it, 0);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, it, 0);
     }
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
@@ -429,6 +417,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->hctx.weight_min = prm.weight_min; h->hctx.conv_deg = prm.conv_deg; h->hctx.conv_cm = prm.conv_cm;
     h->hctx.eig_thresh = prm.eig_thresh; h->hctx.min_corr = prm.min_corr; h->hctx.max_iter = prm.max_iter;
     h->hctx.early_exit = prm.early_exit;
+    if (const char* e = getenv("S2M_ABLATE")) h->hctx.ablate = atoi(e);
     h->ctx_dirty = true;
     if (upload_ctx(h) != S2M_OK) return bail(S2M_ERR_HIP);
     *out = h;
@@ -444,7 +433,7 @@ int s2m_destroy(s2m_handle h)
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
                        &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
-                       &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->sc_bins, &h->sc_out };
+                       &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out };
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (h->h_state) hipHostFree(h->h_state);
     if (h->h_trace) hipHostFree(h->h_trace);
@@ -588,6 +577,31 @@ int s2m_surf_optimization(s2m_handle h, const float pose[6], int32_t* idx5, floa
     return upload_ctx(h);
 }
 
+int s2m_debug_wave_profile(s2m_handle h, const float pose[6], uint64_t* out, size_t cap_waves)
+{
+    if (!h || !pose || !out) return S2M_ERR_INVALID_ARG;
+    if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
+    S2M_HIP(h, hipSetDevice(h->device));
+    const size_t nwaves = (size_t)h->hctx.nblocks * (kBlock / 64);
+    int rc;
+    if ((rc = ensure(h, h->dbg_clk, sizeof(uint64_t) * 8 * nwaves))) return rc;
+    S2M_HIP(h, hipMemsetAsync(h->dbg_clk.p, 0, sizeof(uint64_t) * 8 * nwaves, h->stream));
+    h->hctx.dbg_clk = h->dbg_clk.as<unsigned long long>();
+    h->ctx_dirty = true;
+    if ((rc = upload_ctx(h))) return rc;
+    if ((rc = push_state(h, pose))) return rc;
+    for (int rep = 0; rep < 3; rep++)       // last pass is the warm one
+        hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>());
+    S2M_HIP(h, hipGetLastError());
+    const size_t n = nwaves < cap_waves ? nwaves : cap_waves;
+    S2M_HIP(h, hipMemcpyAsync(out, h->dbg_clk.p, sizeof(uint64_t) * 8 * n, hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    h->hctx.dbg_clk = nullptr;
+    h->ctx_dirty = true;
+    if ((rc = upload_ctx(h))) return rc;
+    return (int)n;
+}
+
 int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6], int32_t* n_sel)
 {
     if (!h || !pose) return S2M_ERR_INVALID_ARG;
@@ -604,7 +618,7 @@ int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6]
     if ((rc = push_state(h, pose))) return rc;
     const DevCtx* dc = h->dctx.as<DevCtx>();
     hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, h->stream, dc, 0, 1);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, 0, 1);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
@@ -617,6 +631,12 @@ int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6]
 int s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float* set_scan_ms)
 {
     if (!h) return S2M_ERR_INVALID_ARG;
+    if (h->scan_timing_pending) {
+        S2M_HIP(h, hipSetDevice(h->device));
+        S2M_HIP(h, hipStreamSynchronize(h->stream));
+        S2M_HIP(h, hipEventElapsedTime(&h->t_set_scan_ms, h->ev_c, h->ev_d));
+        h->scan_timing_pending = false;
+    }
     if (optimize_ms) *optimize_ms = h->t_optimize_ms;
     if (set_map_ms) *set_map_ms = h->t_set_map_ms;
     if (set_scan_ms) *set_scan_ms = h->t_set_scan_ms;

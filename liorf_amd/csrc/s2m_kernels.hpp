@@ -15,6 +15,12 @@ namespace s2m {
 // ------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------
+// Pointers fetched from the DevCtx block in memory are generic to the compiler, and generic
+// (flat_*) loads return out of order, forcing vmcnt(0)+lgkmcnt(0) at every use. G() states
+// that they point to global memory so that global_load/global_store with counted waits are used.
+template <typename T> using gptr = __attribute__((address_space(1))) T*;
+template <typename T> __device__ __forceinline__ gptr<T> G(T* p) { return (gptr<T>)p; }
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint32_t f2ord(float f)
 {
     uint32_t u = __float_as_uint(f);
@@ -40,9 +46,11 @@ __device__ __forceinline__ void swap_if(bool c, int& a, int& b)
 // ------------------------------------------------------------------------------------------
 // index build: bounding box, cell histogram with per-point rank, exclusive scan, scatter
 // ------------------------------------------------------------------------------------------
-// mm[0..2] = ordered-uint min x,y,z ; mm[3..5] = ordered-uint max x,y,z (host initialises)
-__global__ void k_bbox(const unsigned char* __restrict__ pts, size_t stride, int n, uint32_t* mm)
+// mm[0..2] = ordered-uint min x,y,z ; mm[3..5] = ordered-uint max x,y,z (host initialises).
+// Grid-stride over a small grid, workgroup tree first: 6 same-address atomics per workgroup.
+__global__ __launch_bounds__(256) void k_bbox(const unsigned char* __restrict__ pts, size_t stride, int n, uint32_t* mm)
 {
+    __shared__ float smn[4][3], smx[4][3];
     float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
@@ -60,12 +68,18 @@ __global__ void k_bbox(const unsigned char* __restrict__ pts, size_t stride, int
             mx[d] = fmaxf(mx[d], __shfl_down(mx[d], off, 64));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            atomicMin(&mm[d], f2ord(mn[d]));
-            atomicMax(&mm[3 + d], f2ord(mx[d]));
-        }
+        for (int d = 0; d < 3; d++) { smn[wave][d] = mn[d]; smx[wave][d] = mx[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        float a = fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d]));
+        float b = fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]));
+        atomicMin(&mm[d], f2ord(a));
+        atomicMax(&mm[3 + d], f2ord(b));
     }
 }
 
@@ -74,16 +88,78 @@ __device__ __forceinline__ int lin_rows(const GridDesc& g, int cx, int cy, int c
 {
     return (cz * g.ny + cy) * g.nx + cx;
 }
-// linear cell id: 4x4x4 tile-major (scan grid: 64 consecutive ids are one compact block;
-// requires nx,ny,nz to be multiples of 4)
-__device__ __forceinline__ int lin_tiles(const GridDesc& g, int cx, int cy, int cz)
+// Scan locality order (ordering only, never results): lidar returns are binned on a
+// log-polar grid around the sensor (256 azimuth x 128 log-range bins; cell size grows with
+// range like the return spacing does, so cells hold a few points each and the rank atomics
+// do not pile up on the dense near-field cells), numbered along a Z-order curve so that 64
+// consecutive sorted points form a compact patch; a rigid transform keeps it compact.
+constexpr int kPolarCells = 65536;
+__device__ __forceinline__ uint32_t part1by1(uint32_t n)
 {
-    int tx = cx >> 2, ty = cy >> 2, tz = cz >> 2;
-    int tile = (tz * (g.ny >> 2) + ty) * (g.nx >> 2) + tx;
-    return (tile << 6) | ((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3);
+    n &= 0xffffu; n = (n | (n << 8)) & 0x00FF00FFu; n = (n | (n << 4)) & 0x0F0F0F0Fu;
+    n = (n | (n << 2)) & 0x33333333u; n = (n | (n << 1)) & 0x55555555u; return n;
+}
+__device__ __forceinline__ int polar_cell(float x, float y)
+{
+    const float rho = sqrtf(x * x + y * y);
+    float az = atan2f(y, x);                                  // [-pi, pi]
+    int ab = (int)((az + 3.14159265f) * (256.0f / 6.2831853f));
+    ab = min(max(ab, 0), 255);
+    float lr = (__log2f(fmaxf(rho, 0.5f)) + 1.0f) * (128.0f / 9.23f);   // 0.5 m .. 300 m
+    int rb = (rho == rho) ? min(max((int)lr, 0), 127) : 0;
+    if (!(az == az)) ab = 0;
+    return (int)(part1by1((uint32_t)ab) | (part1by1((uint32_t)rb) << 1));
 }
 
-template <bool TILED>
+__global__ void k_polar_count(const unsigned char* __restrict__ pts, size_t stride, int n,
+                              int32_t* __restrict__ cell_of, int32_t* __restrict__ rank_of,
+                              int32_t* __restrict__ counts)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
+    const int c = polar_cell(p[0], p[1]);
+    cell_of[i] = c;
+    rank_of[i] = atomicAdd(&counts[c], 1);
+}
+
+// exclusive scan of the 65536 polar cell counts by one workgroup (64 per thread)
+__global__ __launch_bounds__(1024) void k_polar_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ start)
+{
+    __shared__ int32_t wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int32_t v[64];
+    int32_t sum = 0;
+    const int4* c4 = reinterpret_cast<const int4*>(counts + t * 64);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int4 q = c4[k];
+        v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+        sum += q.x + q.y + q.z + q.w;
+    }
+    int32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int32_t woff = 0;
+    for (int w = 0; w < wave; w++) woff += wsum[w];
+    int32_t run = woff + incl - sum;
+    int4* s4 = reinterpret_cast<int4*>(start + t * 64);
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int4 q;
+        q.x = run; run += v[4 * k];
+        q.y = run; run += v[4 * k + 1];
+        q.z = run; run += v[4 * k + 2];
+        q.w = run; run += v[4 * k + 3];
+        s4[k] = q;
+    }
+}
+
 __global__ void k_bin_count(const unsigned char* __restrict__ pts, size_t stride, int n, GridDesc g,
                             int32_t* __restrict__ cell_of, int32_t* __restrict__ rank_of,
                             int32_t* __restrict__ counts)
@@ -94,7 +170,7 @@ __global__ void k_bin_count(const unsigned char* __restrict__ pts, size_t stride
     int cx = cell_coord(p[0], g.ox, g.inv_e, g.nx);
     int cy = cell_coord(p[1], g.oy, g.inv_e, g.ny);
     int cz = cell_coord(p[2], g.oz, g.inv_e, g.nz);
-    int c = TILED ? lin_tiles(g, cx, cy, cz) : lin_rows(g, cx, cy, cz);
+    int c = lin_rows(g, cx, cy, cz);
     cell_of[i] = c;
     rank_of[i] = atomicAdd(&counts[c], 1);
 }
@@ -336,12 +412,22 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // ------------------------------------------------------------------------------------------
 // k_register: one launch = one surfOptimization() pass (:1074-1143) fused with the matA/matB
 // row assembly of LMOptimization() (:1191-1235) and the first stage of the AtA / AtB
-// reduction (:1237-1239).  One lane = one scan point:
-//   p_sel = T p_ori  ->  exact 5-NN over the 3x3x3 cell neighbourhood (9 contiguous x-runs of
-//   the cell-sorted map)  ->  gate  ->  LS plane  ->  inlier test  ->  weight  ->  Jacobian row
-//   ->  21+6+1 fp64 sums per lane  ->  wave shuffle + LDS reduction  ->  one partial per workgroup.
+// reduction (:1237-1239).  One lane = one scan point, one wave = 64 locality-sorted points:
+//
+//   p_sel = T p_ori -> wave bounding box of the lanes' grid cells (+1 halo) -> the map rows
+//   that box covers are staged into the wave's LDS tile (cell offsets + float4 points; rows
+//   are contiguous runs of the cell-sorted map, so the copies coalesce), in chunks when the
+//   box holds more than the tile -> every lane walks its own 3x3x3 cell neighbourhood (9 x-runs)
+//   inside the tile keeping an exact top-5 by (d2, map index) -> gate -> LS plane -> inlier
+//   test -> weight -> Jacobian row -> 21+6+1 fp64 products per lane -> wave shuffle + LDS
+//   reduction -> one partial per workgroup.
+//
+// No barrier is needed until the final reduction: a wave only reads LDS it wrote itself.
 // combineOptimizationCoeffs() (:1145-1156) has no counterpart: rejected lanes contribute zeros.
 // ------------------------------------------------------------------------------------------
+constexpr int kTilePts = 512;        // points per wave tile   (8 KiB)
+constexpr int kTileCells = 768;      // cell offsets per tile  (3 KiB)
+
 struct Top5 {
     uint64_t key[5];    // (fp32 d2 bits << 32) | original map index: one u64 compare orders (d2, idx)
     int32_t  pos[5];    // position in the cell-sorted map (to re-read the coordinates)
@@ -359,73 +445,208 @@ __device__ __forceinline__ void top5_insert(Top5& t, uint64_t key, int32_t pos)
     }
 }
 
+__device__ __forceinline__ void consider(Top5& best, const v4f m, int32_t gpos, float sx, float sy, float sz)
+{
+    const float dx = sx - m.x, dy = sy - m.y, dz = sz - m.z;
+    const float d2 = (dx * dx + dy * dy) + dz * dz;                                   // L2_Simple order
+    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(m.w);
+    if (key < best.key[4]) top5_insert(best, key, gpos);
+}
+
+// LDS written by this wave is read back by other lanes of the same wave: DS operations of one
+// wave execute in order, so only the compiler has to be kept from reordering them.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <bool HOOK>
 __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ cp)
 {
-    const DevState* __restrict__ st = cp->state;
+    const auto st = G((const DevState*)cp->state);
     if (!HOOK && st->done) return;
 
-    const int tid = threadIdx.x;
+    __shared__ v4f     s_pts[kBlock / 64][kTilePts + 4];
+    __shared__ int32_t s_cs[kBlock / 64][kTileCells];
+    __shared__ int32_t s_rstart[kBlock / 64][64], s_roff[kBlock / 64][64], s_rlen[kBlock / 64][64];
+    __shared__ double  red[kBlock / 64][kAcc];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * kBlock + tid;
     const int nq = cp->n_q;
+    const bool valid = i < nq;
+    v4f*     lpts = s_pts[wave];
+    int32_t* lcs = s_cs[wave];
+    int32_t* lrs = s_rstart[wave];
+    int32_t* lro = s_roff[wave];
+    int32_t* lrl = s_rlen[wave];
 
+    const GridDesc g = cp->g;
+    const auto map = G((const v4f*)cp->map_sorted);
+    const auto cell_start = G(cp->cell_start);
+
+    float px = 0.0f, py = 0.0f, pz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    int cx = 0, cy = 0, cz = 0;
+    if (valid) {
+        px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
+        // pointAssociateToMap (:302-308), association order of the reference expression
+        sx = ((st->T[0] * px + st->T[1] * py) + st->T[2]  * pz) + st->T[3];
+        sy = ((st->T[4] * px + st->T[5] * py) + st->T[6]  * pz) + st->T[7];
+        sz = ((st->T[8] * px + st->T[9] * py) + st->T[10] * pz) + st->T[11];
+        cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
+        cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
+        cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
+    }
+
+    Top5 best;
+#pragma unroll
+    for (int k = 0; k < 5; k++) { best.key[k] = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu; best.pos[k] = 0; }
+
+    // ---- wave bounding box of the lanes' cells (butterfly, every lane gets the result)
+    int lo[3] = { valid ? cx : 0x7fffffff, valid ? cy : 0x7fffffff, valid ? cz : 0x7fffffff };
+    int hi[3] = { valid ? cx : -1, valid ? cy : -1, valid ? cz : -1 };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            lo[d] = min(lo[d], __shfl_xor(lo[d], off, 64));
+            hi[d] = max(hi[d], __shfl_xor(hi[d], off, 64));
+        }
+    }
+
+    const int ablate = cp->ablate;
+    unsigned long long clk0 = 0, clk1 = 0, clk2 = 0;
+    int dbg_chunks = 0, dbg_rows = 0, dbg_pts = 0;
+    if (HOOK) clk0 = wall_clock64();
+    if (hi[0] >= 0 && !(ablate & 8)) {                                                // wave-uniform
+        const int bx0 = max(lo[0] - 1, 0), bx1 = min(hi[0] + 1, g.nx - 1);
+        const int by0 = max(lo[1] - 1, 0), by1 = min(hi[1] + 1, g.ny - 1);
+        const int bz0 = max(lo[2] - 1, 0), bz1 = min(hi[2] + 1, g.nz - 1);
+        const int W = bx1 - bx0 + 2;                      // cell offsets per row (fence-post)
+        const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
+        const int R = nyb * nzb;                          // rows in the box
+        if (HOOK) dbg_rows = R;
+        const int xo0 = max(cx - 1, 0) - bx0;             // this lane's x-run inside a row
+        const int xo1 = min(cx + 1, g.nx - 1) + 1 - bx0;
+
+        for (int rg = 0; rg < R; rg += 64) {              // row groups: one row per lane
+            const int nrows = min(64, R - rg);
+            int rstart = 0, len = 0;
+            if (lane < nrows) {
+                const int r = rg + lane;
+                const int zz = bz0 + r / nyb, yy = by0 + r - (r / nyb) * nyb;
+                const int rb = (zz * g.ny + yy) * g.nx;
+                rstart = cell_start[rb + bx0];
+                len = cell_start[rb + bx1 + 1] - rstart;
+            }
+            int incl = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            const int roff = incl - len;                  // exclusive prefix of the row lengths
+            wave_lds_sync();                              // previous group's readers are done
+            lrs[lane] = rstart; lro[lane] = roff; lrl[lane] = len;
+            wave_lds_sync();
+
+            int c0 = 0;
+            while (c0 < nrows) {                          // chunks of rows that fit the tile
+                const int base = lro[c0];
+                const bool fits = lane >= c0 && lane < nrows && (roff + len - base) <= kTilePts &&
+                                  (lane - c0 + 1) * W <= kTileCells;
+                const unsigned long long notfit = ~__ballot(fits) & (~0ull << c0);
+                int c1 = notfit ? (int)__builtin_ctzll(notfit) : 64;
+                c1 = min(c1, nrows);
+
+                if (c1 == c0) {
+                    // a single row larger than the tile: its lanes read it straight from the map
+                    c1 = c0 + 1;
+                    if (valid) {
+                        const int r = rg + c0;
+                        const int zz = bz0 + r / nyb, yy = by0 + r - (r / nyb) * nyb;
+                        if (abs(zz - cz) <= 1 && abs(yy - cy) <= 1) {
+                            const int rb = (zz * g.ny + yy) * g.nx;
+                            const int s = cell_start[rb + xo0 + bx0], e = cell_start[rb + xo1 + bx0];
+                            for (int j = s; j < e; j++) consider(best, map[j], j, sx, sy, sz);
+                        }
+                    }
+                    c0 = c1;
+                    continue;
+                }
+
+                // ---- stage: cell offsets (tile-relative) ...
+                if (HOOK) { dbg_chunks++; dbg_pts += lro[c1 - 1] + lrl[c1 - 1] - base; }
+                const int ncl = (c1 - c0) * W;
+                for (int f = lane; f < ncl; f += 64) {
+                    const int cr = f / W, x = f - cr * W;
+                    const int r = rg + c0 + cr;
+                    const int zz = bz0 + r / nyb, yy = by0 + r - (r / nyb) * nyb;
+                    const int rb = (zz * g.ny + yy) * g.nx;
+                    lcs[f] = cell_start[rb + bx0 + x] - lrs[c0 + cr] + (lro[c0 + cr] - base);
+                }
+                // ---- ... and points: 16 lanes per row, 4 rows per pass
+                {
+                    const int sub = lane >> 4, l16 = lane & 15;
+                    for (int c = c0 + sub; c < c1; c += 4) {
+                        const int s = lrs[c], o = lro[c] - base, n = lrl[c];
+                        for (int k = l16; k < n; k += 16) lpts[o + k] = map[s + k];
+                    }
+                }
+                wave_lds_sync();
+
+                // ---- search: this lane's runs that fall in rows [c0, c1) of this group
+                if (valid && !(ablate & 1)) {
+#pragma unroll 1
+                    for (int k = 0; k < 9; k++) {
+                        // centre row first so the 5th-best bound tightens early
+                        // (dy,dz) = (0,0),(-1,0),(1,0),(0,-1),(0,1),(-1,-1),(1,-1),(-1,1),(1,1), 2 bits each
+                        const int dyc = (int)((139617u >> (2 * k)) & 3u) - 1;
+                        const int dzc = (int)((164373u >> (2 * k)) & 3u) - 1;
+                        const int yy = cy + dyc, zz = cz + dzc;
+                        if (yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz) continue;
+                        const int rr = (zz - bz0) * nyb + (yy - by0) - rg;
+                        if (rr < c0 || rr >= c1) continue;
+                        const int rl = (rr - c0) * W;
+                        const int s = lcs[rl + xo0], e = lcs[rl + xo1];
+                        const int delta = lrs[rr] - (lro[rr] - base);     // map position - tile position
+                        int j = s;
+                        for (; j + 4 <= e; j += 4) {
+                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                            consider(best, m0, j + delta, sx, sy, sz);
+                            consider(best, m1, j + 1 + delta, sx, sy, sz);
+                            consider(best, m2, j + 2 + delta, sx, sy, sz);
+                            consider(best, m3, j + 3 + delta, sx, sy, sz);
+                        }
+                        for (; j < e; j++) consider(best, lpts[j], j + delta, sx, sy, sz);
+                    }
+                }
+                wave_lds_sync();                          // tile is free for the next chunk
+                c0 = c1;
+            }
+        }
+    }
+
+    if (HOOK) clk1 = wall_clock64();
     double acc[kAcc];
 #pragma unroll
     for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
 
-    if (i < nq) {
-        const GridDesc g = cp->g;
-        const float4* __restrict__ map = cp->map_sorted;
-        const int32_t* __restrict__ cell_start = cp->cell_start;
-
-        const float px = cp->qx[i], py = cp->qy[i], pz = cp->qz[i];               // pointOri (:1085)
-        // pointAssociateToMap (:302-308), association order of the reference expression
-        const float sx = ((st->T[0] * px + st->T[1] * py) + st->T[2]  * pz) + st->T[3];
-        const float sy = ((st->T[4] * px + st->T[5] * py) + st->T[6]  * pz) + st->T[7];
-        const float sz = ((st->T[8] * px + st->T[9] * py) + st->T[10] * pz) + st->T[11];
-
-        const int cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
-        const int cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
-        const int cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-
-        Top5 best;
-#pragma unroll
-        for (int k = 0; k < 5; k++) { best.key[k] = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu; best.pos[k] = 0; }
-
-        for (int dzc = -1; dzc <= 1; dzc++) {
-            const int zz = cz + dzc;
-            if (zz < 0 || zz >= g.nz) continue;
-            for (int dyc = -1; dyc <= 1; dyc++) {
-                const int yy = cy + dyc;
-                if (yy < 0 || yy >= g.ny) continue;
-                const int rowbase = (zz * g.ny + yy) * g.nx;
-                const int s = cell_start[rowbase + x0];
-                const int e = cell_start[rowbase + x1 + 1];
-                for (int j = s; j < e; j++) {
-                    const float4 m = map[j];
-                    const float dx = sx - m.x, dy = sy - m.y, dz = sz - m.z;
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;                 // L2_Simple order
-                    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(m.w);
-                    if (key < best.key[4]) top5_insert(best, key, j);
-                }
-            }
-        }
-
+    if (valid) {
         const float d2_4 = __uint_as_float((uint32_t)(best.key[4] >> 32));
-        const bool gated = (double)d2_4 < cp->gate_sq;                              // :1097
+        const bool gated = ((double)d2_4 < cp->gate_sq) && !(ablate & 2);           // :1097
         bool keep = false;
         float cf[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (gated) {
-            float qr[5][3];
+            float qr[5][3], nb[5][3];
 #pragma unroll
             for (int j = 0; j < 5; j++) {
-                const float4 m = map[best.pos[j]];
+                const v4f m = map[best.pos[j]];
                 qr[j][0] = m.x; qr[j][1] = m.y; qr[j][2] = m.z;                      // :1099-1101
+                nb[j][0] = m.x; nb[j][1] = m.y; nb[j][2] = m.z;
             }
-            float nb[5][3];
-#pragma unroll
-            for (int j = 0; j < 5; j++) { nb[j][0] = qr[j][0]; nb[j][1] = qr[j][1]; nb[j][2] = qr[j][2]; }
             float X[3];
             plane_fit_5x3(qr, X);                                                    // :1104
             float pa = X[0], pb = X[1], pc = X[2], pd = 1.0f;
@@ -463,26 +684,26 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         }
 
         if (HOOK) {
-            const int o = cp->qperm[i];
+            const int o = G(cp->qperm)[i];
             if (cp->dbg_idx5) {
 #pragma unroll
-                for (int j = 0; j < 5; j++) cp->dbg_idx5[5 * (size_t)o + j] = gated ? (int32_t)(uint32_t)(best.key[j] & 0xffffffffu) : -1;
+                for (int j = 0; j < 5; j++) G(cp->dbg_idx5)[5 * (size_t)o + j] = gated ? (int32_t)(uint32_t)(best.key[j] & 0xffffffffu) : -1;
             }
             if (cp->dbg_d2) {
 #pragma unroll
-                for (int j = 0; j < 5; j++) cp->dbg_d2[5 * (size_t)o + j] = __uint_as_float((uint32_t)(best.key[j] >> 32));
+                for (int j = 0; j < 5; j++) G(cp->dbg_d2)[5 * (size_t)o + j] = __uint_as_float((uint32_t)(best.key[j] >> 32));
             }
-            if (cp->dbg_flag) cp->dbg_flag[o] = keep ? 1 : 0;
+            if (cp->dbg_flag) G(cp->dbg_flag)[o] = keep ? 1 : 0;
             if (cp->dbg_coeff) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) cp->dbg_coeff[4 * (size_t)o + j] = cf[j];
+                for (int j = 0; j < 4; j++) G(cp->dbg_coeff)[4 * (size_t)o + j] = cf[j];
             }
         }
     }
 
+    if (HOOK) clk2 = wall_clock64();
     // ---- workgroup reduction: wave shuffle tree, then the 4 waves through LDS in fixed order
-    __shared__ double red[kBlock / 64][kAcc];
-    const int lane = tid & 63, wave = tid >> 6;
+    if (ablate & 4) { if (tid < kAcc) G(cp->partials)[(size_t)blockIdx.x * kAcc + tid] = acc[0] + acc[27]; return; }
 #pragma unroll
     for (int k = 0; k < kAcc; k++) {
         double v = acc[k];
@@ -490,10 +711,15 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
         if (lane == 0) red[wave][k] = v;
     }
+    if (HOOK && cp->dbg_clk && lane == 0) {
+        const auto d = G(cp->dbg_clk) + 8 * ((size_t)blockIdx.x * (kBlock / 64) + wave);
+        d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
+        d[4] = (unsigned long long)dbg_chunks; d[5] = (unsigned long long)dbg_rows; d[6] = (unsigned long long)dbg_pts; d[7] = 0;
+    }
     __syncthreads();
     if (tid < kAcc) {
         const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
-        cp->partials[(size_t)blockIdx.x * kAcc + tid] = s;
+        G(cp->partials)[(size_t)blockIdx.x * kAcc + tid] = s;
     }
 }
 
@@ -679,29 +905,44 @@ __device__ void pose_to_transform(const float (&t)[6], float* T, float* sc)
 // It leaves the next iteration's transform in DevState, so the 30-iteration loop (:1304-1315)
 // never returns to the host.  mode 1 = normal equations only (observation hook).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(const DevCtx* __restrict__ cp, int iter, int mode)
+__device__ __forceinline__ void store_trace(gptr<s2m_iter_trace> dst, const s2m_iter_trace& tr)
 {
-    DevState* st = cp->state;
+    dst->n_sel = tr.n_sel; dst->stepped = tr.stepped; dst->deltaR = tr.deltaR; dst->deltaT = tr.deltaT;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dst->delta[k] = tr.delta[k]; dst->pose[k] = tr.pose[k]; }
+}
+
+__global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restrict__ cp, int iter, int mode)
+{
+    const auto st = G(cp->state);
+    const auto trace = G(cp->trace);
     if (mode == 0 && st->done) return;
 
-    __shared__ double part[8][32];
+    __shared__ double part[kFinThreads / 32][32];
     __shared__ double tot[32];
     __shared__ float eA[6][6], eV[6][6], eVi[6][6], eV2[6][6], eW[6];
     __shared__ int eR[6], eC[6];
 
+    constexpr int NG = kFinThreads / 32;                // row groups
     const int t = threadIdx.x, col = t & 31, grp = t >> 5;
     double s = 0.0;
     if (col < kAcc) {
-        const double* __restrict__ P = cp->partials;
+        const auto P = G((const double*)cp->partials);
         const int nb = cp->nblocks;
-        for (int b = grp; b < nb; b += 8) s += P[(size_t)b * kAcc + col];
+        for (int b0 = grp; b0 < nb; b0 += 8 * NG) {      // 8 independent loads in flight per lane
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int b = b0 + u * NG; v[u] = (b < nb) ? P[(size_t)b * kAcc + col] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
     }
     part[grp][col] = s;
     __syncthreads();
     if (t < kAcc) {
         double v = 0.0;
 #pragma unroll
-        for (int g2 = 0; g2 < 8; g2++) v += part[g2][t];
+        for (int g2 = 0; g2 < NG; g2++) v += part[g2][t];
         tot[t] = v;
     }
     __syncthreads();
@@ -734,7 +975,7 @@ __global__ __launch_bounds__(256) void k_finalize(const DevCtx* __restrict__ cp,
     if (n_sel < cp->min_corr) {                         // :1178-1180: false, pose unchanged;
         st->stalled = 1; st->done = 1;                  // the remaining iterations repeat this no-op
         st->iters_run = cp->max_iter;
-        cp->trace[iter] = tr;
+        store_trace(trace + iter, tr);
         return;
     }
 
@@ -781,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_finalize(const DevCtx* __restrict__ cp,
     tr.stepped = 1; tr.deltaR = deltaR; tr.deltaT = deltaT;
 #pragma unroll
     for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; st->pose[k] = pose[k]; }
-    cp->trace[iter] = tr;
+    store_trace(trace + iter, tr);
 
     float T[12], sc[6];
     pose_to_transform(pose, T, sc);
@@ -793,6 +1034,11 @@ __global__ __launch_bounds__(256) void k_finalize(const DevCtx* __restrict__ cp,
     if (conv && !st->converged) st->converged = 1;
     if (conv && cp->early_exit) st->done = 1;           // break (:1313-1314)
 }
+
+// Parameter blocks travel as kernel arguments (copied at launch), so the host never has to
+// keep a staging buffer alive or synchronise to update them.
+__global__ void k_set_ctx(DevCtx* dst, DevCtx v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
+__global__ void k_set_state(DevState* dst, DevState v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
 
 // ------------------------------------------------------------------------------------------
 // ScanContext descriptor (include/Scancontext.cpp:151-211): max-z polar histogram, 20 rings x

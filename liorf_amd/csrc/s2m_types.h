@@ -9,6 +9,7 @@ namespace s2m {
 
 constexpr int kBlock = 256;            // threads per workgroup of the registration kernel (4 waves)
 constexpr int kAcc = 28;               // 21 upper-triangular JtJ + 6 Jtr + 1 correspondence count
+constexpr int kFinThreads = 512;       // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
 constexpr int kBlocksQuantum = 16;     // graph cache key granularity (workgroups)
 
@@ -53,8 +54,10 @@ struct DevCtx {
     double gate_sq, plane_tol, weight_scale, weight_min, conv_deg, conv_cm;
     float  eig_thresh;
     int32_t min_corr, max_iter, early_exit;
+    int32_t ablate;               // diagnostics only (env S2M_ABLATE): 1 skip search, 2 skip plane/Jacobian, 4 skip reduction, 8 skip staging
     // observation outputs of the hook variant (original scan order), may be null
     int32_t* dbg_idx5; float* dbg_d2; uint8_t* dbg_flag; float* dbg_coeff;
+    unsigned long long* dbg_clk;  // [nwaves][8] per-wave wall-clock stamps + tile stats (diagnostics)
 };
 
 }  // namespace s2m

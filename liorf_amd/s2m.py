@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device",
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
-    "s2m_time_iteration_kernel", "s2m_make_scancontext",
+    "s2m_time_iteration_kernel", "s2m_make_scancontext", "s2m_debug_wave_profile",
 ]
 
 
@@ -91,6 +91,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_normal_eq.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_int32)]
     L.s2m_last_timing.argtypes = [vp, fp, fp, fp]
     L.s2m_time_iteration_kernel.argtypes = [vp, fp, C.c_int, fp]
+    L.s2m_debug_wave_profile.argtypes = [vp, fp, C.POINTER(C.c_uint64), C.c_size_t]
     L.s2m_make_scancontext.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if path is None:
         _LIB = L
@@ -160,6 +161,15 @@ class MapOptimizationS2M:
         a, n, st = _records(laserCloudSurfLastDS)
         self._check(self.lib.s2m_set_scan(self.h, a.ctypes.data, n, st), "s2m_set_scan")
         self.laserCloudSurfLastDSNum = n
+
+    def setScanDevice(self, d_ptr: int, n: int, stride_bytes: int):
+        """s2m_set_scan_device: the scan already lives in HBM (asynchronous; the buffer must stay
+        valid until the next synchronising call, e.g. collect())."""
+        self._check(self.lib.s2m_set_scan_device(self.h, C.c_void_p(d_ptr), n, stride_bytes), "s2m_set_scan_device")
+        self.laserCloudSurfLastDSNum = n
+
+    def setInputCloudDevice(self, d_ptr: int, n: int, stride_bytes: int):
+        self._check(self.lib.s2m_set_map_device(self.h, C.c_void_p(d_ptr), n, stride_bytes), "s2m_set_map_device")
 
     # -- the path ----------------------------------------------------------
     def scan2MapOptimization(self, imu: ImuInit | None = None) -> Result:
@@ -238,6 +248,16 @@ class MapOptimizationS2M:
         ms = C.c_float(0)
         self._check(self.lib.s2m_time_iteration_kernel(self.h, _fp(p), reps, C.byref(ms)), "s2m_time_iteration_kernel")
         return ms.value
+
+    def wave_profile(self, pose) -> np.ndarray:
+        """Diagnostics: (n_waves, 8) uint64 per-wave stamps/stats of one k_register pass."""
+        p = np.ascontiguousarray(pose, np.float32)
+        cap = (self.laserCloudSurfLastDSNum + 63) // 64 + 64
+        out = np.zeros((cap, 8), np.uint64)
+        n = self.lib.s2m_debug_wave_profile(self.h, _fp(p), out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
+        if n < 0:
+            self._check(n, "s2m_debug_wave_profile")
+        return out[:n]
 
     def makeScancontext(self, scan):
         """SCManager::makeScancontext + makeRingkeyFromScancontext (reference include/Scancontext.cpp:151-211)."""

@@ -1,0 +1,29 @@
+"""Diagnostics: time k_register on the kitti64 workload (optionally with S2M_ABLATE bits set)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from liorf_amd import s2m, synth
+name = sys.argv[1] if len(sys.argv) > 1 else "kitti64"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+cfg = synth.make_config(name)
+eng = s2m.MapOptimizationS2M(early_exit=0)
+eng.setInputCloud(synth.to_xyzi(cfg["map"]))
+eng.setScan(synth.to_xyzi(cfg["scan"]))
+ms = eng.time_iteration_kernel(cfg["pose_init"], reps)
+print("ablate=%s k_register %.2f us" % (os.environ.get("S2M_ABLATE", "0"), ms * 1e3))
+if os.environ.get("S2M_WAVES"):
+    w = eng.wave_profile(cfg["pose_init"]).astype(np.int64)
+    w = w[w[:, 0] > 0]
+    t0 = w[:, 0].min()
+    search, plane, red = (w[:, 1] - w[:, 0]) / 100.0, (w[:, 2] - w[:, 1]) / 100.0, (w[:, 3] - w[:, 2]) / 100.0
+    tot = (w[:, 3] - w[:, 0]) / 100.0
+    print("waves", len(w), "kernel span us", (w[:, 3].max() - t0) / 100.0, "start spread us", (w[:, 0].max() - t0) / 100.0)
+    for name, a in (("stage+search", search), ("plane+jac", plane), ("reduce", red), ("total", tot)):
+        print("%-13s med %.2f p90 %.2f p99 %.2f max %.2f us" % (name, np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max()))
+    o = np.argsort(-tot)[:8]
+    print("slowest waves: total_us chunks rows pts start_us")
+    for i in o:
+        print("   %.2f %d %d %d %.2f" % (tot[i], w[i, 4], w[i, 5], w[i, 6], (w[i, 0] - t0) / 100.0))
+    one = w[:, 4] == 1
+    print("single-chunk waves: search med %.2f p99 %.2f; pts med %d" % (np.median(search[one]), np.percentile(search[one], 99), np.median(w[one, 6])))
+    np.save("gpurun_out/waves.npy", w)
