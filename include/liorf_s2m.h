@@ -166,9 +166,10 @@ int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float*
  * between two HIP events on the handle's stream; returns mean ms per launch. */
 int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float* ms_per_launch);
 
-/* Diagnostics: one k_register pass at `pose`; per wave (64 locality-sorted scan points) 8 words:
- * wall-clock (100 MHz) at start / after the tile search / after plane+Jacobian / at end, then
- * tile chunks, box rows, staged points, 0. Returns the number of waves written (<= cap_waves). */
+/* Diagnostics: one k_register pass at `pose`; per wave (64 locality-sorted scan points) 16 words:
+ * wall-clock (100 MHz) at start / after the search / after plane+Jacobian / at end; search path
+ * (1 LDS tile, 2 gather), box rows, points visited, 0; ticks spent in prior+box / row marking /
+ * (unused) / staging / search; 3 spare. Returns the number of waves written (<= cap_waves). */
 int  s2m_debug_wave_profile(s2m_handle h, const float pose[6], uint64_t* out, size_t cap_waves);
 
 /* ---- ScanContext descriptor (BASELINE config 5) ------------------------- */

@@ -91,13 +91,25 @@ __device__ __forceinline__ int lin_rows(const GridDesc& g, int cx, int cy, int c
 // Scan locality order (ordering only, never results): lidar returns are binned on a
 // log-polar grid around the sensor (256 azimuth x 128 log-range bins; cell size grows with
 // range like the return spacing does, so cells hold a few points each and the rank atomics
-// do not pile up on the dense near-field cells), numbered along a Z-order curve so that 64
+// do not pile up on the dense near-field cells), numbered along a Hilbert curve so that 64
 // consecutive sorted points form a compact patch; a rigid transform keeps it compact.
 constexpr int kPolarCells = 65536;
-__device__ __forceinline__ uint32_t part1by1(uint32_t n)
+// Hilbert curve index of (x, y) on a 256 x 256 grid: consecutive indices are always adjacent
+// cells (a Z-order curve jumps across the grid at every power-of-two boundary, and a wave that
+// straddles a jump gets a huge bounding box).
+__device__ __forceinline__ uint32_t hilbert256(uint32_t x, uint32_t y)
 {
-    n &= 0xffffu; n = (n | (n << 8)) & 0x00FF00FFu; n = (n | (n << 4)) & 0x0F0F0F0Fu;
-    n = (n | (n << 2)) & 0x33333333u; n = (n | (n << 1)) & 0x55555555u; return n;
+    uint32_t d = 0;
+#pragma unroll
+    for (uint32_t s = 128; s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += s * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) { x = 255u - x; y = 255u - y; }
+            const uint32_t t = x; x = y; y = t;
+        }
+    }
+    return d;
 }
 __device__ __forceinline__ int polar_cell(float x, float y)
 {
@@ -108,7 +120,7 @@ __device__ __forceinline__ int polar_cell(float x, float y)
     float lr = (__log2f(fmaxf(rho, 0.5f)) + 1.0f) * (128.0f / 9.23f);   // 0.5 m .. 300 m
     int rb = (rho == rho) ? min(max((int)lr, 0), 127) : 0;
     if (!(az == az)) ab = 0;
-    return (int)(part1by1((uint32_t)ab) | (part1by1((uint32_t)rb) << 1));
+    return (int)hilbert256((uint32_t)ab, (uint32_t)rb);
 }
 
 __global__ void k_polar_count(const unsigned char* __restrict__ pts, size_t stride, int n,
@@ -244,13 +256,15 @@ __global__ __launch_bounds__(256) void k_scan_add(int32_t* __restrict__ out, con
 
 __global__ void k_scatter_map(const unsigned char* __restrict__ pts, size_t stride, int n,
                               const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
-                              const int32_t* __restrict__ cell_start, float4* __restrict__ map_sorted)
+                              const int32_t* __restrict__ cell_start, float4* __restrict__ map_sorted,
+                              float4* __restrict__ map_orig)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
     int pos = cell_start[cell_of[i]] + rank_of[i];
     map_sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
+    map_orig[i] = make_float4(p[0], p[1], p[2], 0.0f);      // original order: the 5 neighbours are re-read by index
 }
 
 __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t stride, int n,
@@ -414,43 +428,64 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // row assembly of LMOptimization() (:1191-1235) and the first stage of the AtA / AtB
 // reduction (:1237-1239).  One lane = one scan point, one wave = 64 locality-sorted points:
 //
-//   p_sel = T p_ori -> wave bounding box of the lanes' grid cells (+1 halo) -> the map rows
-//   that box covers are staged into the wave's LDS tile (cell offsets + float4 points; rows
-//   are contiguous runs of the cell-sorted map, so the copies coalesce), in chunks when the
-//   box holds more than the tile -> every lane walks its own 3x3x3 cell neighbourhood (9 x-runs)
-//   inside the tile keeping an exact top-5 by (d2, map index) -> gate -> LS plane -> inlier
-//   test -> weight -> Jacobian row -> 21+6+1 fp64 products per lane -> wave shuffle + LDS
-//   reduction -> one partial per workgroup.
+//   p_sel = T p_ori
+//   -> PRIOR: the 5 neighbours this point had in the previous launch (any 5 distinct map points
+//      would do) are re-measured; their 5th distance is an exact upper bound on this launch's
+//      5th-neighbour distance, so map rows and cells whose slab is farther away are never
+//      touched.  The LM loop revisits the same scan up to 30 times with an ever smaller pose
+//      step, so from the second launch on the bound is tight and the search collapses.
+//   -> wave bounding box of the lanes' grid cells (+1 halo, DPP min/max)
+//   -> TILE path (compact waves, the common case): the map rows of the box that some lane still
+//      needs are staged into the wave's LDS tile (each row is one contiguous run of the
+//      cell-sorted map, so the copies coalesce; 8 rows are in flight per pass) and every lane
+//      sweeps the whole tile (uniform loop, LDS broadcast reads).  A superset of a lane's 3x3x3
+//      cells cannot change its gated result: anything outside them is farther than the gate.
+//   -> GATHER path (sparse waves, big boxes): each lane reads the <= 9 x-runs of its own 3x3x3
+//      neighbourhood straight from the L2-resident cell-sorted map; all run bounds are fetched
+//      up front, runs and cells beyond the bound are skipped.
+//   -> exact top-5 by (d2, map index) -> gate -> LS plane -> inlier test -> weight -> Jacobian
+//   row -> 21+6+1 fp64 products per lane -> recursive-halving wave reduction + LDS across the
+//   4 waves -> one partial per workgroup.
 //
 // No barrier is needed until the final reduction: a wave only reads LDS it wrote itself.
 // combineOptimizationCoeffs() (:1145-1156) has no counterpart: rejected lanes contribute zeros.
 // ------------------------------------------------------------------------------------------
-constexpr int kTilePts = 512;        // points per wave tile   (8 KiB)
-constexpr int kTileCells = 768;      // cell offsets per tile  (3 KiB)
+constexpr int kTilePts = 128;        // points per wave tile (2 KiB); larger boxes take the gather path
+constexpr int kRowLoop = 48;         // boxes up to this many rows are candidates for the tile path
+constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning (<= 5e-5)
+constexpr uint64_t kKeyInf = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu;
 
-struct Top5 {
-    uint64_t key[5];    // (fp32 d2 bits << 32) | original map index: one u64 compare orders (d2, idx)
-    int32_t  pos[5];    // position in the cell-sorted map (to re-read the coordinates)
-};
+struct Top5 { uint64_t key[5]; };    // (fp32 d2 bits << 32) | original map index, ascending
 
-__device__ __forceinline__ void top5_insert(Top5& t, uint64_t key, int32_t pos)
+__device__ __forceinline__ void top5_insert(Top5& t, uint64_t key)
 {
-    t.key[4] = key; t.pos[4] = pos;
+    t.key[4] = key;
 #pragma unroll
     for (int j = 4; j > 0; --j) {
-        const bool c = t.key[j] < t.key[j - 1];
         const uint64_t ka = t.key[j - 1], kb = t.key[j];
+        const bool c = kb < ka;
         t.key[j - 1] = c ? kb : ka; t.key[j] = c ? ka : kb;
-        swap_if(c, t.pos[j - 1], t.pos[j]);
     }
 }
 
-__device__ __forceinline__ void consider(Top5& best, const v4f m, int32_t gpos, float sx, float sy, float sz)
+__device__ __forceinline__ uint64_t make_key(const v4f m, float sx, float sy, float sz, float& d2)
 {
     const float dx = sx - m.x, dy = sy - m.y, dz = sz - m.z;
-    const float d2 = (dx * dx + dy * dy) + dz * dz;                                   // L2_Simple order
-    const uint64_t key = ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(m.w);
-    if (key < best.key[4]) top5_insert(best, key, gpos);
+    d2 = (dx * dx + dy * dy) + dz * dz;                                               // L2_Simple order
+    return ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(m.w);
+}
+
+__device__ __forceinline__ void consider(Top5& best, float& worst, const v4f m, float sx, float sy, float sz)
+{
+    float d2;
+    const uint64_t key = make_key(m, sx, sy, sz, d2);
+    const uint32_t idx = (uint32_t)key;
+    // one straight-line predicate, one branch. A map point already in the set (the prior's points
+    // are met again; the gather path re-reads the last point of a run) has the same index.
+    const bool pass = (d2 <= worst) & (key < best.key[4]) &
+                      (idx != (uint32_t)best.key[0]) & (idx != (uint32_t)best.key[1]) &
+                      (idx != (uint32_t)best.key[2]) & (idx != (uint32_t)best.key[3]);
+    if (pass) { top5_insert(best, key); worst = __uint_as_float((uint32_t)(best.key[4] >> 32)); }
 }
 
 // LDS written by this wave is read back by other lanes of the same wave: DS operations of one
@@ -462,34 +497,89 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// wave64 reductions / scan on the DPP cross-lane path (VALU rate, no LDS round trips):
+// row_shr 1,2,4,8 inside the 16-lane rows, row_bcast:15 into rows 1 and 3, row_bcast:31 into
+// rows 2 and 3; lane 63 then holds the result.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int src)
+{
+    return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_min_i32(int v)
+{
+    constexpr int ID = 0x7fffffff;
+    v = min(v, dpp_i32<0x111, 0xf>(ID, v)); v = min(v, dpp_i32<0x112, 0xf>(ID, v));
+    v = min(v, dpp_i32<0x114, 0xf>(ID, v)); v = min(v, dpp_i32<0x118, 0xf>(ID, v));
+    v = min(v, dpp_i32<0x142, 0xa>(ID, v)); v = min(v, dpp_i32<0x143, 0xc>(ID, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+    constexpr int ID = (int)0x80000000;
+    v = max(v, dpp_i32<0x111, 0xf>(ID, v)); v = max(v, dpp_i32<0x112, 0xf>(ID, v));
+    v = max(v, dpp_i32<0x114, 0xf>(ID, v)); v = max(v, dpp_i32<0x118, 0xf>(ID, v));
+    v = max(v, dpp_i32<0x142, 0xa>(ID, v)); v = max(v, dpp_i32<0x143, 0xc>(ID, v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t u)
+{
+    int v = (int)u;
+    v |= dpp_i32<0x111, 0xf>(0, v); v |= dpp_i32<0x112, 0xf>(0, v);
+    v |= dpp_i32<0x114, 0xf>(0, v); v |= dpp_i32<0x118, 0xf>(0, v);
+    v |= dpp_i32<0x142, 0xa>(0, v); v |= dpp_i32<0x143, 0xc>(0, v);
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v)
+{
+    v += dpp_i32<0x111, 0xf>(0, v); v += dpp_i32<0x112, 0xf>(0, v);
+    v += dpp_i32<0x114, 0xf>(0, v); v += dpp_i32<0x118, 0xf>(0, v);
+    v += dpp_i32<0x142, 0xa>(0, v); v += dpp_i32<0x143, 0xc>(0, v);
+    return v;
+}
+
+// (dy,dz) of the 9 rows of a 3x3x3 neighbourhood, centre row first so that the 5th-best bound
+// tightens early: (0,0),(-1,0),(1,0),(0,-1),(0,1),(-1,-1),(1,-1),(-1,1),(1,1), 2 bits each
+__device__ __forceinline__ int run_dy(int k) { return (int)((139617u >> (2 * k)) & 3u) - 1; }
+__device__ __forceinline__ int run_dz(int k) { return (int)((164373u >> (2 * k)) & 3u) - 1; }
+
 template <bool HOOK>
 __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ cp)
 {
     const auto st = G((const DevState*)cp->state);
     if (!HOOK && st->done) return;
+    unsigned long long tk_start = 0, tk = 0, t_bbox = 0, t_mark = 0, t_stage = 0, t_search = 0;
+    if (HOOK) { tk_start = wall_clock64(); tk = tk_start; }
+#define S2M_LAP(acc) do { if (HOOK) { const unsigned long long n__ = wall_clock64(); (acc) += n__ - tk; tk = n__; } } while (0)
 
-    __shared__ v4f     s_pts[kBlock / 64][kTilePts + 4];
-    __shared__ int32_t s_cs[kBlock / 64][kTileCells];
-    __shared__ int32_t s_rstart[kBlock / 64][64], s_roff[kBlock / 64][64], s_rlen[kBlock / 64][64];
-    __shared__ double  red[kBlock / 64][kAcc];
+    constexpr int NW = kBlock / 64;
+    __shared__ v4f     s_pts[NW][kTilePts];
+    __shared__ int32_t s_run[NW][18][64];            // gather path: this lane's 9 (start, end) pairs
+    __shared__ double  red[NW][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x * kBlock + tid;
     const int nq = cp->n_q;
     const bool valid = i < nq;
-    v4f*     lpts = s_pts[wave];
-    int32_t* lcs = s_cs[wave];
-    int32_t* lrs = s_rstart[wave];
-    int32_t* lro = s_roff[wave];
-    int32_t* lrl = s_rlen[wave];
+    v4f* lpts = s_pts[wave];
 
     const GridDesc g = cp->g;
     const auto map = G((const v4f*)cp->map_sorted);
+    const auto mo = G((const v4f*)cp->map_orig);
     const auto cell_start = G(cp->cell_start);
+    const auto prev5 = G(cp->prev5);
+    const int ablate = cp->ablate;
 
     float px = 0.0f, py = 0.0f, pz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
     int cx = 0, cy = 0, cz = 0;
+    Top5 best;
+#pragma unroll
+    for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
+    float worst = INFINITY;
+
+    int pidx[5] = { -1, -1, -1, -1, -1 };
     if (valid) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) pidx[j] = prev5[(size_t)j * nq + i];
         px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
         // pointAssociateToMap (:302-308), association order of the reference expression
         sx = ((st->T[0] * px + st->T[1] * py) + st->T[2]  * pz) + st->T[3];
@@ -498,165 +588,234 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
         cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
         cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
-    }
-
-    Top5 best;
+        if (pidx[0] >= 0 && !(ablate & 16)) {            // prior: 5 distinct map points
+            v4f pm[5];
 #pragma unroll
-    for (int k = 0; k < 5; k++) { best.key[k] = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu; best.pos[k] = 0; }
-
-    // ---- wave bounding box of the lanes' cells (butterfly, every lane gets the result)
-    int lo[3] = { valid ? cx : 0x7fffffff, valid ? cy : 0x7fffffff, valid ? cz : 0x7fffffff };
-    int hi[3] = { valid ? cx : -1, valid ? cy : -1, valid ? cz : -1 };
+            for (int j = 0; j < 5; j++) pm[j] = mo[pidx[j]];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
+            for (int j = 0; j < 5; j++) {
+                float d2;
+                v4f m = pm[j]; m.w = __int_as_float(pidx[j]);
+                top5_insert(best, make_key(m, sx, sy, sz, d2));
+            }
+            worst = __uint_as_float((uint32_t)(best.key[4] >> 32));
+            if (!(worst == worst)) {                     // NaN distance: drop the prior
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-            lo[d] = min(lo[d], __shfl_xor(lo[d], off, 64));
-            hi[d] = max(hi[d], __shfl_xor(hi[d], off, 64));
+                for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
+                worst = INFINITY;
+            }
         }
     }
 
-    const int ablate = cp->ablate;
-    unsigned long long clk0 = 0, clk1 = 0, clk2 = 0;
-    int dbg_chunks = 0, dbg_rows = 0, dbg_pts = 0;
-    if (HOOK) clk0 = wall_clock64();
-    if (hi[0] >= 0 && !(ablate & 8)) {                                                // wave-uniform
-        const int bx0 = max(lo[0] - 1, 0), bx1 = min(hi[0] + 1, g.nx - 1);
-        const int by0 = max(lo[1] - 1, 0), by1 = min(hi[1] + 1, g.ny - 1);
-        const int bz0 = max(lo[2] - 1, 0), bz1 = min(hi[2] + 1, g.nz - 1);
-        const int W = bx1 - bx0 + 2;                      // cell offsets per row (fence-post)
+    // ---- wave bounding box of the lanes' cells
+    const int blx = wave_min_i32(valid ? cx : 0x7fffffff), bhx = wave_max_i32(valid ? cx : -1);
+    const int bly = wave_min_i32(valid ? cy : 0x7fffffff), bhy = wave_max_i32(valid ? cy : -1);
+    const int blz = wave_min_i32(valid ? cz : 0x7fffffff), bhz = wave_max_i32(valid ? cz : -1);
+
+    unsigned long long clk1 = 0, clk2 = 0;
+    int dbg_mode = 0, dbg_rows = 0, dbg_pts = 0;
+    S2M_LAP(t_bbox);
+
+    if (bhx >= 0 && !(ablate & 8)) {                                                  // wave-uniform
+        const int bx0 = max(blx - 1, 0), bx1 = min(bhx + 1, g.nx - 1);
+        const int by0 = max(bly - 1, 0), by1 = min(bhy + 1, g.ny - 1);
+        const int bz0 = max(blz - 1, 0), bz1 = min(bhz + 1, g.nz - 1);
         const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
         const int R = nyb * nzb;                          // rows in the box
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);      // this lane's cells in a row
         if (HOOK) dbg_rows = R;
-        const int xo0 = max(cx - 1, 0) - bx0;             // this lane's x-run inside a row
-        const int xo1 = min(cx + 1, g.nx - 1) + 1 - bx0;
 
-        for (int rg = 0; rg < R; rg += 64) {              // row groups: one row per lane
-            const int nrows = min(64, R - rg);
-            int rstart = 0, len = 0;
-            if (lane < nrows) {
-                const int r = rg + lane;
-                const int zz = bz0 + r / nyb, yy = by0 + r - (r / nyb) * nyb;
-                const int rb = (zz * g.ny + yy) * g.nx;
-                rstart = cell_start[rb + bx0];
-                len = cell_start[rb + bx1 + 1] - rstart;
-            }
-            int incl = len;
+        // squared slab distances of this query to the faces of its own cell: lower bounds of the
+        // distance to anything in the neighbouring row / cell on that side (see kSlabMargin)
+        const float E = g.e;
+        const float xlo = g.ox + (float)cx * E, ylo = g.oy + (float)cy * E, zlo = g.oz + (float)cz * E;
+        const float gxm = fmaxf(sx - xlo - kSlabMargin, 0.0f), gxp = fmaxf(xlo + E - sx - kSlabMargin, 0.0f);
+        const float gym = fmaxf(sy - ylo - kSlabMargin, 0.0f), gyp = fmaxf(ylo + E - sy - kSlabMargin, 0.0f);
+        const float gzm = fmaxf(sz - zlo - kSlabMargin, 0.0f), gzp = fmaxf(zlo + E - sz - kSlabMargin, 0.0f);
+        const float gx2m = gxm * gxm * 0.9999f, gx2p = gxp * gxp * 0.9999f;
+        const float gy2m = gym * gym * 0.9999f, gy2p = gyp * gyp * 0.9999f;
+        const float gz2m = gzm * gzm * 0.9999f, gz2p = gzp * gzp * 0.9999f;
+
+        // ---- tile path? mark the box rows some lane still needs, size them, decide
+        bool tile = false;
+        int gs = 0, len = 0, poff = 0, ptot = 0;          // lane r: row r of the box
+        if (R <= kRowLoop && !(ablate & 64)) {
+            // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
+            unsigned long long need = 0ull;
+            if (valid) {
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
+                for (int k = 0; k < 9; k++) {
+                    const int dyc = run_dy(k), dzc = run_dz(k);
+                    const int yy = cy + dyc, zz = cz + dzc;
+                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > worst))
+                        need |= 1ull << ((zz - bz0) * nyb + (yy - by0));
+                }
             }
-            const int roff = incl - len;                  // exclusive prefix of the row lengths
-            wave_lds_sync();                              // previous group's readers are done
-            lrs[lane] = rstart; lro[lane] = roff; lrl[lane] = len;
+            const uint32_t nlo = wave_or_u32((uint32_t)need), nhi = wave_or_u32((uint32_t)(need >> 32));
+            const bool mine = (((lane < 32) ? (nlo >> lane) : (nhi >> (lane - 32))) & 1u) != 0u;
+            if (mine) {                                   // whole rows: a compact wave's box is narrow in x
+                const int zq = lane / nyb;
+                const int gcell = ((bz0 + zq) * g.ny + by0 + (lane - zq * nyb)) * g.nx;
+                gs = cell_start[gcell + bx0];
+                len = cell_start[gcell + bx1 + 1] - gs;
+            }
+            const int incl = wave_incl_scan_i32(len);
+            poff = incl - len;
+            ptot = __builtin_amdgcn_readlane(incl, 63);
+            tile = ptot <= kTilePts;
+        }
+        S2M_LAP(t_mark);
+
+        if (tile) {
+            if (HOOK) { dbg_mode = 1; dbg_pts = ptot; }
+            // ---- stage: 16 lanes per row, 8 rows in flight per pass
+            const int sub = lane >> 4, l16 = lane & 15;
+            for (int cb = 0; cb < R; cb += 8) {
+                const int ca = cb + sub, cc = cb + 4 + sub;              // < 64: R <= kRowLoop
+                const int gsa = __shfl(gs, ca, 64), na = __shfl(len, ca, 64), poa = __shfl(poff, ca, 64);
+                const int gsc = __shfl(gs, cc, 64), nn = __shfl(len, cc, 64), poc = __shfl(poff, cc, 64);
+                v4f pa_v = { 0, 0, 0, 0 }, pc_v = { 0, 0, 0, 0 };
+                if (l16 < na) pa_v = map[gsa + l16];
+                if (l16 < nn) pc_v = map[gsc + l16];
+                if (l16 < na) lpts[poa + l16] = pa_v;
+                if (l16 < nn) lpts[poc + l16] = pc_v;
+                for (int k = l16 + 16; k < na; k += 16) lpts[poa + k] = map[gsa + k];
+                for (int k = l16 + 16; k < nn; k += 16) lpts[poc + k] = map[gsc + k];
+            }
             wave_lds_sync();
-
-            int c0 = 0;
-            while (c0 < nrows) {                          // chunks of rows that fit the tile
-                const int base = lro[c0];
-                const bool fits = lane >= c0 && lane < nrows && (roff + len - base) <= kTilePts &&
-                                  (lane - c0 + 1) * W <= kTileCells;
-                const unsigned long long notfit = ~__ballot(fits) & (~0ull << c0);
-                int c1 = notfit ? (int)__builtin_ctzll(notfit) : 64;
-                c1 = min(c1, nrows);
-
-                if (c1 == c0) {
-                    // a single row larger than the tile: its lanes read it straight from the map
-                    c1 = c0 + 1;
-                    if (valid) {
-                        const int r = rg + c0;
-                        const int zz = bz0 + r / nyb, yy = by0 + r - (r / nyb) * nyb;
-                        if (abs(zz - cz) <= 1 && abs(yy - cy) <= 1) {
-                            const int rb = (zz * g.ny + yy) * g.nx;
-                            const int s = cell_start[rb + xo0 + bx0], e = cell_start[rb + xo1 + bx0];
-                            for (int j = s; j < e; j++) consider(best, map[j], j, sx, sy, sz);
-                        }
-                    }
-                    c0 = c1;
-                    continue;
+            S2M_LAP(t_stage);
+            // ---- sweep: every lane, every tile point
+            if (!(ablate & 1)) {
+                int j = 0;
+                for (; j + 4 <= ptot; j += 4) {
+                    const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                    consider(best, worst, m0, sx, sy, sz);
+                    consider(best, worst, m1, sx, sy, sz);
+                    consider(best, worst, m2, sx, sy, sz);
+                    consider(best, worst, m3, sx, sy, sz);
                 }
-
-                // ---- stage: cell offsets (tile-relative) ...
-                if (HOOK) { dbg_chunks++; dbg_pts += lro[c1 - 1] + lrl[c1 - 1] - base; }
-                const int ncl = (c1 - c0) * W;
-                for (int f = lane; f < ncl; f += 64) {
-                    const int cr = f / W, x = f - cr * W;
-                    const int r = rg + c0 + cr;
-                    const int zz = bz0 + r / nyb, yy = by0 + r - (r / nyb) * nyb;
-                    const int rb = (zz * g.ny + yy) * g.nx;
-                    lcs[f] = cell_start[rb + bx0 + x] - lrs[c0 + cr] + (lro[c0 + cr] - base);
-                }
-                // ---- ... and points: 16 lanes per row, 4 rows per pass
-                {
-                    const int sub = lane >> 4, l16 = lane & 15;
-                    for (int c = c0 + sub; c < c1; c += 4) {
-                        const int s = lrs[c], o = lro[c] - base, n = lrl[c];
-                        for (int k = l16; k < n; k += 16) lpts[o + k] = map[s + k];
-                    }
-                }
-                wave_lds_sync();
-
-                // ---- search: this lane's runs that fall in rows [c0, c1) of this group
-                if (valid && !(ablate & 1)) {
-#pragma unroll 1
-                    for (int k = 0; k < 9; k++) {
-                        // centre row first so the 5th-best bound tightens early
-                        // (dy,dz) = (0,0),(-1,0),(1,0),(0,-1),(0,1),(-1,-1),(1,-1),(-1,1),(1,1), 2 bits each
-                        const int dyc = (int)((139617u >> (2 * k)) & 3u) - 1;
-                        const int dzc = (int)((164373u >> (2 * k)) & 3u) - 1;
-                        const int yy = cy + dyc, zz = cz + dzc;
-                        if (yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz) continue;
-                        const int rr = (zz - bz0) * nyb + (yy - by0) - rg;
-                        if (rr < c0 || rr >= c1) continue;
-                        const int rl = (rr - c0) * W;
-                        const int s = lcs[rl + xo0], e = lcs[rl + xo1];
-                        const int delta = lrs[rr] - (lro[rr] - base);     // map position - tile position
-                        int j = s;
-                        for (; j + 4 <= e; j += 4) {
-                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                            consider(best, m0, j + delta, sx, sy, sz);
-                            consider(best, m1, j + 1 + delta, sx, sy, sz);
-                            consider(best, m2, j + 2 + delta, sx, sy, sz);
-                            consider(best, m3, j + 3 + delta, sx, sy, sz);
-                        }
-                        for (; j < e; j++) consider(best, lpts[j], j + delta, sx, sy, sz);
-                    }
-                }
-                wave_lds_sync();                          // tile is free for the next chunk
-                c0 = c1;
+                for (; j < ptot; j++) consider(best, worst, lpts[j], sx, sy, sz);
             }
+            S2M_LAP(t_search);
+        } else {
+            if (HOOK) dbg_mode = 2;
+            // ---- gather: run bounds of all 9 rows first (independent loads), then the runs
+            int32_t (*lrun)[64] = s_run[wave];
+            if (valid) {
+                int rs[9], re[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int dyc = run_dy(k), dzc = run_dz(k);
+                    const int yy = cy + dyc, zz = cz + dzc;
+                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
+                    rs[k] = 0; re[k] = 0;
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > worst)) {
+                        const int xs = (x0 < cx && lb + gx2m <= worst) ? x0 : cx;     // left cell still reachable?
+                        const int xe = (x1 > cx && lb + gx2p <= worst) ? x1 : cx;     // right cell?
+                        const int rb = (zz * g.ny + yy) * g.nx;
+                        rs[k] = cell_start[rb + xs];
+                        re[k] = cell_start[rb + xe + 1];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) { lrun[2 * k][lane] = rs[k]; lrun[2 * k + 1][lane] = re[k]; }
+            }
+            wave_lds_sync();
+            S2M_LAP(t_stage);
+            if (valid && !(ablate & 1)) {
+                // software pipeline: the first 4 points of run k+1 are in flight while run k is
+                // processed (past a run's end its last point is re-read: a dup, rejected for free)
+                int jn = lrun[0][lane], en = lrun[1][lane];
+                v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
+                if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+#pragma unroll 1
+                for (int k = 0; k < 9; k++) {
+                    int j = jn; const int e = en;
+                    const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
+                    if (k < 8) {
+                        jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
+                        if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+                    }
+                    if (j >= e) continue;
+                    const int dyc = run_dy(k), dzc = run_dz(k);
+                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
+                    if (lb > worst) continue;                                          // bound tightened meanwhile
+                    if (HOOK) dbg_pts += e - j;
+                    consider(best, worst, m0, sx, sy, sz);
+                    consider(best, worst, m1, sx, sy, sz);
+                    consider(best, worst, m2, sx, sy, sz);
+                    consider(best, worst, m3, sx, sy, sz);
+                    for (j += 4; j < e; j += 4) {   // long runs: 4 loads in flight
+                        const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
+                        consider(best, worst, q0, sx, sy, sz);
+                        consider(best, worst, q1, sx, sy, sz);
+                        consider(best, worst, q2, sx, sy, sz);
+                        consider(best, worst, q3, sx, sy, sz);
+                    }
+                }
+            }
+            S2M_LAP(t_search);
         }
     }
 
     if (HOOK) clk1 = wall_clock64();
-    double acc[kAcc];
+    double acc[32];
 #pragma unroll
-    for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+    for (int k = 0; k < 32; k++) acc[k] = 0.0;
 
     if (valid) {
+        // this launch's neighbours are the next launch's prior (only a complete set is usable)
+        const bool full = best.key[4] != kKeyInf;
+        uint32_t nidx[5];
+        bool same = full;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            nidx[j] = (uint32_t)(best.key[j] & 0xffffffffu);
+            same = same && ((int32_t)nidx[j] == pidx[j]);
+        }
+        if (!same) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) prev5[(size_t)j * nq + i] = full ? (int32_t)nidx[j] : -1;
+        }
+
         const float d2_4 = __uint_as_float((uint32_t)(best.key[4] >> 32));
         const bool gated = ((double)d2_4 < cp->gate_sq) && !(ablate & 2);           // :1097
         bool keep = false;
         float cf[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (gated) {
-            float qr[5][3], nb[5][3];
+            // The LS plane and its inlier test depend only on the ordered neighbour tuple, not on
+            // the pose: a point that kept its 5 neighbours re-uses last launch's plane bit for bit.
+            const auto pcache = G((v4f*)cp->plane_cache);
+            const auto pstate = G(cp->plane_state);
+            float pa, pb, pc, pd;
+            bool planeValid;
+            const int pst = (same && !(ablate & 32)) ? pstate[i] : 0;
+            if (pst != 0) {
+                const v4f pl = pcache[i];
+                pa = pl.x; pb = pl.y; pc = pl.z; pd = pl.w; planeValid = (pst == 1);
+            } else {
+                float qr[5][3], nb[5][3];
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const v4f m = map[best.pos[j]];
-                qr[j][0] = m.x; qr[j][1] = m.y; qr[j][2] = m.z;                      // :1099-1101
-                nb[j][0] = m.x; nb[j][1] = m.y; nb[j][2] = m.z;
-            }
-            float X[3];
-            plane_fit_5x3(qr, X);                                                    // :1104
-            float pa = X[0], pb = X[1], pc = X[2], pd = 1.0f;
-            const float ps = sqrtf(pa * pa + pb * pb + pc * pc);                      // :1111
-            pa /= ps; pb /= ps; pc /= ps; pd /= ps;
-            bool planeValid = true;
+                for (int j = 0; j < 5; j++) {
+                    const v4f m = mo[nidx[j]];
+                    qr[j][0] = m.x; qr[j][1] = m.y; qr[j][2] = m.z;                  // :1099-1101
+                    nb[j][0] = m.x; nb[j][1] = m.y; nb[j][2] = m.z;
+                }
+                float X[3];
+                plane_fit_5x3(qr, X);                                                // :1104
+                pa = X[0]; pb = X[1]; pc = X[2]; pd = 1.0f;
+                const float ps = sqrtf(pa * pa + pb * pb + pc * pc);                  // :1111
+                pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+                planeValid = true;
 #pragma unroll
-            for (int j = 0; j < 5; j++) {                                            // :1115-1122
-                const float r = pa * nb[j][0] + pb * nb[j][1] + pc * nb[j][2] + pd;
-                if ((double)fabsf(r) > cp->plane_tol) planeValid = false;
+                for (int j = 0; j < 5; j++) {                                        // :1115-1122
+                    const float r = pa * nb[j][0] + pb * nb[j][1] + pc * nb[j][2] + pd;
+                    if ((double)fabsf(r) > cp->plane_tol) planeValid = false;
+                }
+                const v4f pl = { pa, pb, pc, pd };
+                pcache[i] = pl;
+                pstate[i] = planeValid ? 1 : 2;
             }
             if (planeValid) {
                 const float pd2 = pa * sx + pb * sy + pc * sz + pd;                   // :1125
@@ -667,6 +826,8 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                     keep = true;
                 }
             }
+        } else if (!same) {
+            G(cp->plane_state)[i] = 0;
         }
 
         if (keep) {
@@ -702,25 +863,35 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     }
 
     if (HOOK) clk2 = wall_clock64();
-    // ---- workgroup reduction: wave shuffle tree, then the 4 waves through LDS in fixed order
+    // ---- wave reduction by recursive halving: at mask m a lane keeps one half of its sums and
+    // hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
+    // five steps lane l holds, in acc[0], sum number l>>1 over its half-wave pair group, and one
+    // full exchange with lane^1 completes it.  Fixed order: bitwise reproducible.
     if (ablate & 4) { if (tid < kAcc) G(cp->partials)[(size_t)blockIdx.x * kAcc + tid] = acc[0] + acc[27]; return; }
 #pragma unroll
-    for (int k = 0; k < kAcc; k++) {
-        double v = acc[k];
+    for (int h = 16, m = 32; h >= 1; h >>= 1, m >>= 1) {
+        const bool up = (lane & m) != 0;
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wave][k] = v;
+        for (int j = 0; j < h; j++) {
+            const double keepv = up ? acc[j + h] : acc[j];
+            const double sendv = up ? acc[j] : acc[j + h];
+            acc[j] = keepv + __shfl_xor(sendv, m, 64);
+        }
     }
+    acc[0] += __shfl_xor(acc[0], 1, 64);
+    if ((lane & 1) == 0) red[wave][lane >> 1] = acc[0];
     if (HOOK && cp->dbg_clk && lane == 0) {
-        const auto d = G(cp->dbg_clk) + 8 * ((size_t)blockIdx.x * (kBlock / 64) + wave);
-        d[0] = clk0; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
-        d[4] = (unsigned long long)dbg_chunks; d[5] = (unsigned long long)dbg_rows; d[6] = (unsigned long long)dbg_pts; d[7] = 0;
+        const auto d = G(cp->dbg_clk) + 16 * ((size_t)blockIdx.x * NW + wave);
+        d[0] = tk_start; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
+        d[4] = (unsigned long long)dbg_mode; d[5] = (unsigned long long)dbg_rows; d[6] = (unsigned long long)dbg_pts; d[7] = 0;
+        d[8] = t_bbox; d[9] = t_mark; d[10] = 0; d[11] = t_stage; d[12] = t_search; d[13] = 0; d[14] = 0; d[15] = 0;
     }
     __syncthreads();
     if (tid < kAcc) {
         const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
         G(cp->partials)[(size_t)blockIdx.x * kAcc + tid] = s;
     }
+#undef S2M_LAP
 }
 
 // ------------------------------------------------------------------------------------------

@@ -18,6 +18,7 @@ constexpr int kBlocksQuantum = 16;     // graph cache key granularity (workgroup
 struct GridDesc {
     float ox, oy, oz;     // origin (min corner minus one cell)
     float inv_e;          // 1 / E
+    float e;              // E
     int   nx, ny, nz;     // cells per axis
     int   ncells;
 };
@@ -43,9 +44,13 @@ struct DevState {
 struct DevCtx {
     GridDesc g;
     const float4* map_sorted;     // [n_m] x,y,z, original index (bit pattern), cell-sorted
+    const float4* map_orig;       // [n_m] x,y,z in the caller's order
     const int32_t* cell_start;    // [ncells+1]
     const float* qx; const float* qy; const float* qz;   // [n_q] lidar-frame scan, SoA, locality-sorted
     const int32_t* qperm;         // [n_q] sorted position -> original scan index
+    int32_t* prev5;               // [5][n_q] previous launch's neighbours per sorted scan point, -1 = none
+    float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to prev5's tuple
+    int32_t* plane_state;         // [n_q] 0 none, 1 plane passed the inlier test, 2 plane failed it
     int32_t n_q, n_m, nblocks;
     double* partials;             // [nblocks][kAcc]
     DevState* state;
@@ -54,7 +59,7 @@ struct DevCtx {
     double gate_sq, plane_tol, weight_scale, weight_min, conv_deg, conv_cm;
     float  eig_thresh;
     int32_t min_corr, max_iter, early_exit;
-    int32_t ablate;               // diagnostics only (env S2M_ABLATE): 1 skip search, 2 skip plane/Jacobian, 4 skip reduction, 8 skip staging
+    int32_t ablate;               // diagnostics only (env S2M_ABLATE): 1 skip search, 2 skip plane/Jacobian, 4 skip reduction, 8 skip staging, 16 ignore the prior, 32 ignore the plane cache, 64 gather path only
     // observation outputs of the hook variant (original scan order), may be null
     int32_t* dbg_idx5; float* dbg_d2; uint8_t* dbg_flag; float* dbg_coeff;
     unsigned long long* dbg_clk;  // [nwaves][8] per-wave wall-clock stamps + tile stats (diagnostics)

@@ -21,9 +21,16 @@ if os.environ.get("S2M_WAVES"):
     for name, a in (("stage+search", search), ("plane+jac", plane), ("reduce", red), ("total", tot)):
         print("%-13s med %.2f p90 %.2f p99 %.2f max %.2f us" % (name, np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max()))
     o = np.argsort(-tot)[:8]
-    print("slowest waves: total_us chunks rows pts start_us")
+    print("slowest waves: total_us path(1=tile,2=gather) rows pts start_us")
     for i in o:
         print("   %.2f %d %d %d %.2f" % (tot[i], w[i, 4], w[i, 5], w[i, 6], (w[i, 0] - t0) / 100.0))
-    one = w[:, 4] == 1
-    print("single-chunk waves: search med %.2f p99 %.2f; pts med %d" % (np.median(search[one]), np.percentile(search[one], 99), np.median(w[one, 6])))
+    for name, col in (("box", 8), ("mark", 9), ("rows", 10), ("stage", 11), ("search", 12)):
+        a = w[:, col] / 100.0
+        print("  %-7s med %.2f p90 %.2f p99 %.2f max %.2f us" % (name, np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max()))
+    for mode, nm in ((1, "tile"), (2, "gather")):
+        sel = w[:, 4] == mode
+        if sel.any():
+            print("%s waves: %d (%.1f%%) total med %.2f p99 %.2f max %.2f; search med %.2f max %.2f; pts med %d max %d" % (
+                nm, sel.sum(), 100.0 * sel.mean(), np.median(tot[sel]), np.percentile(tot[sel], 99), tot[sel].max(),
+                np.median(w[sel, 12]) / 100.0, w[sel, 12].max() / 100.0, np.median(w[sel, 6]), w[sel, 6].max()))
     np.save("gpurun_out/waves.npy", w)
