@@ -58,7 +58,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from liorf_amd import s2m, synth
+    from liorf_amd import batch, s2m, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -84,8 +84,6 @@ def main():
         tm = eng.timing()
     max_iter = eng.params.max_iter
 
-    rec = torch.zeros(8, dtype=torch.float32, device=dev)
-    gathered = [torch.zeros(8, dtype=torch.float32, device=dev) for _ in range(world)] if world > 1 else None
 
     def step():
         # one scan2MapOptimization(): scan ordering/SoA prep + 30 x {k_register, k_finalize}; the map
@@ -93,9 +91,8 @@ def main():
         eng.setScanDevice(d_scan.data_ptr(), n_q, 32)
         eng.launch(cfg["pose_init"])
         r = eng.collect()
-        if world > 1:      # RCCL all-gather of {pose[6], iters, n_sel} over xGMI
-            rec.copy_(torch.tensor(list(r.pose) + [float(r.iters_run), float(r.n_sel_last)], dtype=torch.float32))
-            dist.all_gather(gathered, rec)
+        if world > 1:      # RCCL all-gather of {pose[6], iters, n_sel} over xGMI: every rank gets all poses
+            batch.gather_records(batch.pack_record(r.pose, r.iters_run, r.n_sel_last)[None, :], world, device=dev)
         return r
 
     def fence():

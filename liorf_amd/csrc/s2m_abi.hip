@@ -42,9 +42,9 @@ struct s2m_context {
     std::string err;
 
     // map side
-    DevBuf raw_map, map_sorted, map_orig, m_counts, m_cell_start, m_cell_of, m_rank_of;
+    DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
     // scan side
-    DevBuf raw_scan, qx, qy, qz, qperm, prev5, plane_cache, plane_state, q_counts, q_cell_start, q_cell_of, q_rank_of;
+    DevBuf raw_scan, qx, qy, qz, qperm, prevp, plane_cache, plane_state, q_counts, q_cell_start, q_cell_of, q_rank_of;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
 
@@ -197,7 +197,6 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
     if (g.ncells <= 0) return fail(h, S2M_ERR_CAPACITY, "map extent too large for the search grid");
 
     if ((rc = ensure(h, h->map_sorted, sizeof(float4) * n))) return rc;
-    if ((rc = ensure(h, h->map_orig, sizeof(float4) * n))) return rc;
     if ((rc = ensure(h, h->m_counts, sizeof(int32_t) * ((size_t)g.ncells + 1)))) return rc;
     if ((rc = ensure(h, h->m_cell_start, sizeof(int32_t) * ((size_t)g.ncells + 1)))) return rc;
     if ((rc = ensure(h, h->m_cell_of, sizeof(int32_t) * n))) return rc;
@@ -211,14 +210,13 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
     if ((rc = device_exclusive_scan(h, h->m_counts.as<int32_t>(), h->m_cell_start.as<int32_t>(), g.ncells, (int)n))) return rc;
     hipLaunchKernelGGL(k_scatter_map, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
                        (const int32_t*)h->m_cell_of.as<int32_t>(), (const int32_t*)h->m_rank_of.as<int32_t>(),
-                       (const int32_t*)h->m_cell_start.as<int32_t>(), h->map_sorted.as<float4>(), h->map_orig.as<float4>());
+                       (const int32_t*)h->m_cell_start.as<int32_t>(), h->map_sorted.as<float4>());
     S2M_HIP(h, hipGetLastError());
 
-    if (h->have_scan && h->n_q > 0 && h->prev5.p)      // neighbour indices of the old map are meaningless now
-        S2M_HIP(h, hipMemsetAsync(h->prev5.p, 0xff, sizeof(int32_t) * 5 * h->n_q, h->stream));
+    if (h->have_scan && h->n_q > 0 && h->prevp.p)      // neighbours of the old map are meaningless now
+        S2M_HIP(h, hipMemsetAsync(h->prevp.p, 0xff, sizeof(float4) * 5 * h->n_q, h->stream));
     h->hctx.g = g;
     h->hctx.map_sorted = h->map_sorted.as<float4>();
-    h->hctx.map_orig = h->map_orig.as<float4>();
     h->hctx.cell_start = h->m_cell_start.as<int32_t>();
     h->ctx_dirty = true;
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
@@ -236,7 +234,8 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
     h->n_q = n; h->have_scan = true;
     h->hctx.n_q = (int32_t)n;
-    int nblocks = (int)((n + kBlock - 1) / kBlock);
+    constexpr int per_block = kWaveQ * (kBlock / 64);
+    int nblocks = (int)((n + per_block - 1) / per_block);
     nblocks = ((nblocks + kBlocksQuantum - 1) / kBlocksQuantum) * kBlocksQuantum;
     if (nblocks == 0) nblocks = kBlocksQuantum;
     h->hctx.nblocks = nblocks;
@@ -257,11 +256,11 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     if ((rc = ensure(h, h->qy, sizeof(float) * n))) return rc;
     if ((rc = ensure(h, h->qz, sizeof(float) * n))) return rc;
     if ((rc = ensure(h, h->qperm, sizeof(int32_t) * n))) return rc;
-    if ((rc = ensure(h, h->prev5, sizeof(int32_t) * 5 * n))) return rc;
+    if ((rc = ensure(h, h->prevp, sizeof(float4) * 5 * n))) return rc;
     if ((rc = ensure(h, h->plane_cache, sizeof(float4) * n))) return rc;
     if ((rc = ensure(h, h->plane_state, sizeof(int32_t) * n))) return rc;
     S2M_HIP(h, hipMemsetAsync(h->plane_state.p, 0, sizeof(int32_t) * n, h->stream));
-    S2M_HIP(h, hipMemsetAsync(h->prev5.p, 0xff, sizeof(int32_t) * 5 * n, h->stream));   // no prior for a new scan
+    S2M_HIP(h, hipMemsetAsync(h->prevp.p, 0xff, sizeof(float4) * 5 * n, h->stream));   // no prior for a new scan (index -1)
     if ((rc = ensure(h, h->q_counts, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
@@ -281,7 +280,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
 
     h->hctx.qx = h->qx.as<float>(); h->hctx.qy = h->qy.as<float>(); h->hctx.qz = h->qz.as<float>();
     h->hctx.qperm = h->qperm.as<int32_t>();
-    h->hctx.prev5 = h->prev5.as<int32_t>();
+    h->hctx.prevp = h->prevp.as<float4>();
     h->hctx.plane_cache = h->plane_cache.as<float4>();
     h->hctx.plane_state = h->plane_state.as<int32_t>();
     h->ctx_dirty = true;
@@ -425,6 +424,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->hctx.partials = h->partials.as<double>();
     h->hctx.state = h->state.as<DevState>();
     h->hctx.trace = h->trace.as<s2m_iter_trace>();
+    h->hctx.gate_f = nextafterf((float)prm.gate_sq, INFINITY);
     h->hctx.gate_sq = prm.gate_sq; h->hctx.plane_tol = prm.plane_tol; h->hctx.weight_scale = prm.weight_scale;
     h->hctx.weight_min = prm.weight_min; h->hctx.conv_deg = prm.conv_deg; h->hctx.conv_cm = prm.conv_cm;
     h->hctx.eig_thresh = prm.eig_thresh; h->hctx.min_corr = prm.min_corr; h->hctx.max_iter = prm.max_iter;
@@ -442,8 +442,8 @@ int s2m_destroy(s2m_handle h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
-    DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->map_orig, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
-                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prev5, &h->plane_cache, &h->plane_state, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
+    DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->plane_cache, &h->plane_state, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out };
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
@@ -594,7 +594,7 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], uint64_t* out, siz
     if (!h || !pose || !out) return S2M_ERR_INVALID_ARG;
     if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
     S2M_HIP(h, hipSetDevice(h->device));
-    const size_t nwaves = (size_t)h->hctx.nblocks * (kBlock / 64);
+    const size_t nwaves = (size_t)h->hctx.nblocks * (kBlock / 64);   // kWaveQ points each
     int rc;
     if ((rc = ensure(h, h->dbg_clk, sizeof(uint64_t) * 16 * nwaves))) return rc;
     S2M_HIP(h, hipMemsetAsync(h->dbg_clk.p, 0, sizeof(uint64_t) * 16 * nwaves, h->stream));

@@ -256,15 +256,13 @@ __global__ __launch_bounds__(256) void k_scan_add(int32_t* __restrict__ out, con
 
 __global__ void k_scatter_map(const unsigned char* __restrict__ pts, size_t stride, int n,
                               const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
-                              const int32_t* __restrict__ cell_start, float4* __restrict__ map_sorted,
-                              float4* __restrict__ map_orig)
+                              const int32_t* __restrict__ cell_start, float4* __restrict__ map_sorted)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
     int pos = cell_start[cell_of[i]] + rank_of[i];
     map_sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
-    map_orig[i] = make_float4(p[0], p[1], p[2], 0.0f);      // original order: the 5 neighbours are re-read by index
 }
 
 __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t stride, int n,
@@ -426,45 +424,56 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // ------------------------------------------------------------------------------------------
 // k_register: one launch = one surfOptimization() pass (:1074-1143) fused with the matA/matB
 // row assembly of LMOptimization() (:1191-1235) and the first stage of the AtA / AtB
-// reduction (:1237-1239).  One lane = one scan point, one wave = 64 locality-sorted points:
+// reduction (:1237-1239).  One lane = one scan point, one wave = 64 locality-sorted points.
 //
-//   p_sel = T p_ori
-//   -> PRIOR: the 5 neighbours this point had in the previous launch (any 5 distinct map points
-//      would do) are re-measured; their 5th distance is an exact upper bound on this launch's
-//      5th-neighbour distance, so map rows and cells whose slab is farther away are never
-//      touched.  The LM loop revisits the same scan up to 30 times with an ever smaller pose
-//      step, so from the second launch on the bound is tight and the search collapses.
-//   -> wave bounding box of the lanes' grid cells (+1 halo, DPP min/max)
-//   -> TILE path (compact waves, the common case): the map rows of the box that some lane still
-//      needs are staged into the wave's LDS tile (each row is one contiguous run of the
-//      cell-sorted map, so the copies coalesce; 8 rows are in flight per pass) and every lane
-//      sweeps the whole tile (uniform loop, LDS broadcast reads).  A superset of a lane's 3x3x3
-//      cells cannot change its gated result: anything outside them is farther than the gate.
-//   -> GATHER path (sparse waves, big boxes): each lane reads the <= 9 x-runs of its own 3x3x3
-//      neighbourhood straight from the L2-resident cell-sorted map; all run bounds are fetched
-//      up front, runs and cells beyond the bound are skipped.
-//   -> exact top-5 by (d2, map index) -> gate -> LS plane -> inlier test -> weight -> Jacobian
-//   row -> 21+6+1 fp64 products per lane -> recursive-halving wave reduction + LDS across the
-//   4 waves -> one partial per workgroup.
+// The L2 of this multi-die part starts cold at every kernel boundary (63 % TCC misses were
+// measured on an earlier version), so a dependent global round trip costs 0.5-1 us and the
+// kernel is organised around having few of them per wave:
+//
+//   round trip 1  scan point + PRIOR (the 5 neighbours this point had in the previous launch,
+//                 kept as coordinates + index; any 5 distinct map points would do).  Re-measured
+//                 at the new pose, their 5th distance - capped at the gate, beyond which nothing
+//                 is observable - is an exact upper bound on this launch's 5th-neighbour
+//                 distance: map rows and cells whose slab is farther away are never touched.
+//                 The LM loop revisits the same scan up to 30 times with an ever smaller pose
+//                 step, so from the second launch on the bound is tight.
+//   (DPP)         wave bounding box of the transformed points -> box of grid cells (+1 halo)
+//   TILE path (compact waves, the common case)
+//   round trip 2  bounds of the box rows that some lane still needs
+//   round trip 3  those rows (contiguous runs of the cell-sorted map, coalesced, 8 rows in
+//                 flight) are filtered against the waves's point box grown by the largest
+//                 bound and compacted into the wave's LDS tile; every lane then sweeps the
+//                 tile (uniform loop, LDS broadcast reads).  A superset of a lane's
+//                 neighbourhood cannot change its gated result.
+//   GATHER path (sparse waves, big boxes)
+//   round trip 2  bounds of the <= 9 x-runs of each lane's own 3x3x3 neighbourhood
+//   round trip 3+ two points of every live run per batch (up to 18 loads in flight)
+//   -> exact top-5 by (d2, map index), coordinates carried along -> gate -> LS plane (re-used
+//   bit for bit when the ordered neighbour tuple is unchanged) -> inlier test -> weight ->
+//   Jacobian row -> 21+6+1 fp64 products per lane -> recursive-halving wave reduction + LDS
+//   across the 4 waves -> one partial per workgroup.
 //
 // No barrier is needed until the final reduction: a wave only reads LDS it wrote itself.
 // combineOptimizationCoeffs() (:1145-1156) has no counterpart: rejected lanes contribute zeros.
 // ------------------------------------------------------------------------------------------
-constexpr int kTilePts = 128;        // points per wave tile (2 KiB); larger boxes take the gather path
+constexpr int kTilePts = 128;        // points per wave tile (2 KiB) after filtering
+constexpr int kTileRaw = 640;        // unfiltered points a wave is willing to stream through the filter
 constexpr int kRowLoop = 48;         // boxes up to this many rows are candidates for the tile path
 constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning (<= 5e-5)
 constexpr uint64_t kKeyInf = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu;
 
-struct Top5 { uint64_t key[5]; };    // (fp32 d2 bits << 32) | original map index, ascending
+// exact top-5: key = (fp32 d2 bits << 32) | original map index, ascending; coordinates ride along
+struct Top5 { uint64_t key[5]; float x[5], y[5], z[5]; };
 
-__device__ __forceinline__ void top5_insert(Top5& t, uint64_t key)
+__device__ __forceinline__ void top5_insert(Top5& t, uint64_t key, float x, float y, float z)
 {
-    t.key[4] = key;
+    t.key[4] = key; t.x[4] = x; t.y[4] = y; t.z[4] = z;
 #pragma unroll
     for (int j = 4; j > 0; --j) {
         const uint64_t ka = t.key[j - 1], kb = t.key[j];
         const bool c = kb < ka;
         t.key[j - 1] = c ? kb : ka; t.key[j] = c ? ka : kb;
+        swap_if(c, t.x[j - 1], t.x[j]); swap_if(c, t.y[j - 1], t.y[j]); swap_if(c, t.z[j - 1], t.z[j]);
     }
 }
 
@@ -475,17 +484,21 @@ __device__ __forceinline__ uint64_t make_key(const v4f m, float sx, float sy, fl
     return ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(m.w);
 }
 
-__device__ __forceinline__ void consider(Top5& best, float& worst, const v4f m, float sx, float sy, float sz)
+// bound = min(d2 of the current 5th best, gate): nothing at or beyond the gate is observable
+__device__ __forceinline__ void consider(Top5& best, float& bound, float gatef, const v4f m, float sx, float sy, float sz)
 {
     float d2;
     const uint64_t key = make_key(m, sx, sy, sz, d2);
     const uint32_t idx = (uint32_t)key;
     // one straight-line predicate, one branch. A map point already in the set (the prior's points
     // are met again; the gather path re-reads the last point of a run) has the same index.
-    const bool pass = (d2 <= worst) & (key < best.key[4]) &
+    const bool pass = (d2 <= bound) & (key < best.key[4]) &
                       (idx != (uint32_t)best.key[0]) & (idx != (uint32_t)best.key[1]) &
                       (idx != (uint32_t)best.key[2]) & (idx != (uint32_t)best.key[3]);
-    if (pass) { top5_insert(best, key); worst = __uint_as_float((uint32_t)(best.key[4] >> 32)); }
+    if (pass) {
+        top5_insert(best, key, m.x, m.y, m.z);
+        bound = fminf(__uint_as_float((uint32_t)(best.key[4] >> 32)), gatef);
+    }
 }
 
 // LDS written by this wave is read back by other lanes of the same wave: DS operations of one
@@ -505,13 +518,26 @@ __device__ __forceinline__ int dpp_i32(int old, int src)
 {
     return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
 }
-__device__ __forceinline__ int wave_min_i32(int v)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float old, float src)
 {
-    constexpr int ID = 0x7fffffff;
-    v = min(v, dpp_i32<0x111, 0xf>(ID, v)); v = min(v, dpp_i32<0x112, 0xf>(ID, v));
-    v = min(v, dpp_i32<0x114, 0xf>(ID, v)); v = min(v, dpp_i32<0x118, 0xf>(ID, v));
-    v = min(v, dpp_i32<0x142, 0xa>(ID, v)); v = min(v, dpp_i32<0x143, 0xc>(ID, v));
-    return __builtin_amdgcn_readlane(v, 63);
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_min_f32(float v)      // NaN-free inputs
+{
+    const float ID = INFINITY;
+    v = fminf(v, dpp_f32<0x111, 0xf>(ID, v)); v = fminf(v, dpp_f32<0x112, 0xf>(ID, v));
+    v = fminf(v, dpp_f32<0x114, 0xf>(ID, v)); v = fminf(v, dpp_f32<0x118, 0xf>(ID, v));
+    v = fminf(v, dpp_f32<0x142, 0xa>(ID, v)); v = fminf(v, dpp_f32<0x143, 0xc>(ID, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    const float ID = -INFINITY;
+    v = fmaxf(v, dpp_f32<0x111, 0xf>(ID, v)); v = fmaxf(v, dpp_f32<0x112, 0xf>(ID, v));
+    v = fmaxf(v, dpp_f32<0x114, 0xf>(ID, v)); v = fmaxf(v, dpp_f32<0x118, 0xf>(ID, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xa>(ID, v)); v = fmaxf(v, dpp_f32<0x143, 0xc>(ID, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ int wave_max_i32(int v)
 {
@@ -539,8 +565,8 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v)
 
 // (dy,dz) of the 9 rows of a 3x3x3 neighbourhood, centre row first so that the 5th-best bound
 // tightens early: (0,0),(-1,0),(1,0),(0,-1),(0,1),(-1,-1),(1,-1),(-1,1),(1,1), 2 bits each
-__device__ __forceinline__ int run_dy(int k) { return (int)((139617u >> (2 * k)) & 3u) - 1; }
-__device__ __forceinline__ int run_dz(int k) { return (int)((164373u >> (2 * k)) & 3u) - 1; }
+__device__ __forceinline__ constexpr int run_dy(int k) { return (int)((139617u >> (2 * k)) & 3u) - 1; }
+__device__ __forceinline__ constexpr int run_dz(int k) { return (int)((164373u >> (2 * k)) & 3u) - 1; }
 
 template <bool HOOK>
 __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ cp)
@@ -552,78 +578,81 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
 #define S2M_LAP(acc) do { if (HOOK) { const unsigned long long n__ = wall_clock64(); (acc) += n__ - tk; tk = n__; } } while (0)
 
     constexpr int NW = kBlock / 64;
-    __shared__ v4f     s_pts[NW][kTilePts];
-    __shared__ int32_t s_run[NW][18][64];            // gather path: this lane's 9 (start, end) pairs
-    __shared__ double  red[NW][32];
+    __shared__ v4f    s_pts[NW][kTilePts];
+    __shared__ double red[NW][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x * kBlock + tid;
+    // wave w of workgroup b takes chunk w*gridDim.x + b of 64 sorted points: neighbouring chunks
+    // (similar cost: the sort runs from the dense near field to the sparse far field) land on
+    // different CUs, which evens out both the work and the L2-miss queues
+    const int i = (wave * (int)gridDim.x + (int)blockIdx.x) * kWaveQ + lane;
     const int nq = cp->n_q;
-    const bool valid = i < nq;
+    const bool valid = lane < kWaveQ && i < nq;
     v4f* lpts = s_pts[wave];
 
     const GridDesc g = cp->g;
     const auto map = G((const v4f*)cp->map_sorted);
-    const auto mo = G((const v4f*)cp->map_orig);
     const auto cell_start = G(cp->cell_start);
-    const auto prev5 = G(cp->prev5);
+    const auto prevp = G((v4f*)cp->prevp);
     const int ablate = cp->ablate;
+    const float gatef = cp->gate_f;
 
     float px = 0.0f, py = 0.0f, pz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    int cx = 0, cy = 0, cz = 0;
     Top5 best;
 #pragma unroll
-    for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
-    float worst = INFINITY;
-
+    for (int k = 0; k < 5; k++) { best.key[k] = kKeyInf; best.x[k] = 0.0f; best.y[k] = 0.0f; best.z[k] = 0.0f; }
+    float bound = gatef;
     int pidx[5] = { -1, -1, -1, -1, -1 };
+
     if (valid) {
+        v4f pm[5];
 #pragma unroll
-        for (int j = 0; j < 5; j++) pidx[j] = prev5[(size_t)j * nq + i];
+        for (int j = 0; j < 5; j++) pm[j] = prevp[(size_t)j * nq + i];
         px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
         // pointAssociateToMap (:302-308), association order of the reference expression
         sx = ((st->T[0] * px + st->T[1] * py) + st->T[2]  * pz) + st->T[3];
         sy = ((st->T[4] * px + st->T[5] * py) + st->T[6]  * pz) + st->T[7];
         sz = ((st->T[8] * px + st->T[9] * py) + st->T[10] * pz) + st->T[11];
-        cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
-        cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
-        cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
-        if (pidx[0] >= 0 && !(ablate & 16)) {            // prior: 5 distinct map points
-            v4f pm[5];
 #pragma unroll
-            for (int j = 0; j < 5; j++) pm[j] = mo[pidx[j]];
+        for (int j = 0; j < 5; j++) pidx[j] = __float_as_int(pm[j].w);
+        if (pidx[0] >= 0 && !(ablate & 16)) {            // prior: 5 distinct map points
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 float d2;
-                v4f m = pm[j]; m.w = __int_as_float(pidx[j]);
-                top5_insert(best, make_key(m, sx, sy, sz, d2));
+                top5_insert(best, make_key(pm[j], sx, sy, sz, d2), pm[j].x, pm[j].y, pm[j].z);
             }
-            worst = __uint_as_float((uint32_t)(best.key[4] >> 32));
-            if (!(worst == worst)) {                     // NaN distance: drop the prior
+            const float w5 = __uint_as_float((uint32_t)(best.key[4] >> 32));
+            if (w5 == w5) bound = fminf(w5, gatef);
+            else {                                       // NaN distance: drop the prior
 #pragma unroll
                 for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
-                worst = INFINITY;
             }
         }
     }
 
-    // ---- wave bounding box of the lanes' cells
-    const int blx = wave_min_i32(valid ? cx : 0x7fffffff), bhx = wave_max_i32(valid ? cx : -1);
-    const int bly = wave_min_i32(valid ? cy : 0x7fffffff), bhy = wave_max_i32(valid ? cy : -1);
-    const int blz = wave_min_i32(valid ? cz : 0x7fffffff), bhz = wave_max_i32(valid ? cz : -1);
+    // ---- wave bounding box of the transformed points (non-finite points stay out of it)
+    const bool fin = valid && (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
+    const float mnx = wave_min_f32(fin ? sx : INFINITY), mxx = wave_max_f32(fin ? sx : -INFINITY);
+    const float mny = wave_min_f32(fin ? sy : INFINITY), mxy = wave_max_f32(fin ? sy : -INFINITY);
+    const float mnz = wave_min_f32(fin ? sz : INFINITY), mxz = wave_max_f32(fin ? sz : -INFINITY);
+    const float rmax2 = wave_max_f32(fin ? bound : 0.0f);
 
     unsigned long long clk1 = 0, clk2 = 0;
-    int dbg_mode = 0, dbg_rows = 0, dbg_pts = 0;
+    int dbg_mode = 0, dbg_rows = 0, dbg_pts = 0, dbg_raw = 0, dbg_why = 0, dbg_box = 0, dbg_skip = 0;
     S2M_LAP(t_bbox);
 
-    if (bhx >= 0 && !(ablate & 8)) {                                                  // wave-uniform
-        const int bx0 = max(blx - 1, 0), bx1 = min(bhx + 1, g.nx - 1);
-        const int by0 = max(bly - 1, 0), by1 = min(bhy + 1, g.ny - 1);
-        const int bz0 = max(blz - 1, 0), bz1 = min(bhz + 1, g.nz - 1);
+    if (mnx <= mxx && !(ablate & 8)) {                                                // wave-uniform
+        const int cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
+        const int cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
+        const int cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
+        // cell_coord is monotone: the box of the lanes' cells is the cells of the box corners
+        const int bx0 = max(cell_coord(mnx, g.ox, g.inv_e, g.nx) - 1, 0), bx1 = min(cell_coord(mxx, g.ox, g.inv_e, g.nx) + 1, g.nx - 1);
+        const int by0 = max(cell_coord(mny, g.oy, g.inv_e, g.ny) - 1, 0), by1 = min(cell_coord(mxy, g.oy, g.inv_e, g.ny) + 1, g.ny - 1);
+        const int bz0 = max(cell_coord(mnz, g.oz, g.inv_e, g.nz) - 1, 0), bz1 = min(cell_coord(mxz, g.oz, g.inv_e, g.nz) + 1, g.nz - 1);
         const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
         const int R = nyb * nzb;                          // rows in the box
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);      // this lane's cells in a row
-        if (HOOK) dbg_rows = R;
+        if (HOOK) { dbg_rows = R; dbg_box = ((bx1 - bx0 + 1) << 20) | (nyb << 10) | nzb; dbg_why = (R > kRowLoop) ? 1 : 0; }
 
         // squared slab distances of this query to the faces of its own cell: lower bounds of the
         // distance to anything in the neighbouring row / cell on that side (see kSlabMargin)
@@ -638,17 +667,17 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
 
         // ---- tile path? mark the box rows some lane still needs, size them, decide
         bool tile = false;
-        int gs = 0, len = 0, poff = 0, ptot = 0;          // lane r: row r of the box
+        int gs = 0, len = 0, ptot = 0;                    // lane r: row r of the box
         if (R <= kRowLoop && !(ablate & 64)) {
             // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
             unsigned long long need = 0ull;
-            if (valid) {
+            if (fin) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
                     const int dyc = run_dy(k), dzc = run_dz(k);
                     const int yy = cy + dyc, zz = cz + dzc;
                     const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > worst))
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > bound))
                         need |= 1ull << ((zz - bz0) * nyb + (yy - by0));
                 }
             }
@@ -660,49 +689,67 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                 gs = cell_start[gcell + bx0];
                 len = cell_start[gcell + bx1 + 1] - gs;
             }
-            const int incl = wave_incl_scan_i32(len);
-            poff = incl - len;
-            ptot = __builtin_amdgcn_readlane(incl, 63);
-            tile = ptot <= kTilePts;
+            ptot = __builtin_amdgcn_readlane(wave_incl_scan_i32(len), 63);
+            tile = ptot <= kTileRaw;
+            if (HOOK) { dbg_raw = ptot; if (!tile) dbg_why = 2; }
         }
         S2M_LAP(t_mark);
 
         if (tile) {
-            if (HOOK) { dbg_mode = 1; dbg_pts = ptot; }
-            // ---- stage: 16 lanes per row, 8 rows in flight per pass
+            // ---- stage through the filter: 16 lanes per row, 8 rows in flight per pass; a point
+            // enters the tile only if it lies inside the wave's point box grown by the largest bound
+            const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
+            const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
             const int sub = lane >> 4, l16 = lane & 15;
-            for (int cb = 0; cb < R; cb += 8) {
+            int nt = 0;                                   // tile fill (wave-uniform)
+            bool overflow = false;
+            for (int cb = 0; cb < R && !overflow; cb += 8) {
                 const int ca = cb + sub, cc = cb + 4 + sub;              // < 64: R <= kRowLoop
-                const int gsa = __shfl(gs, ca, 64), na = __shfl(len, ca, 64), poa = __shfl(poff, ca, 64);
-                const int gsc = __shfl(gs, cc, 64), nn = __shfl(len, cc, 64), poc = __shfl(poff, cc, 64);
-                v4f pa_v = { 0, 0, 0, 0 }, pc_v = { 0, 0, 0, 0 };
-                if (l16 < na) pa_v = map[gsa + l16];
-                if (l16 < nn) pc_v = map[gsc + l16];
-                if (l16 < na) lpts[poa + l16] = pa_v;
-                if (l16 < nn) lpts[poc + l16] = pc_v;
-                for (int k = l16 + 16; k < na; k += 16) lpts[poa + k] = map[gsa + k];
-                for (int k = l16 + 16; k < nn; k += 16) lpts[poc + k] = map[gsc + k];
+                const int gsa = __shfl(gs, ca, 64), na = __shfl(len, ca, 64);
+                const int gsc = __shfl(gs, cc, 64), nn = __shfl(len, cc, 64);
+                const int nmax = max(na, nn);
+                const int npass = wave_max_i32(nmax);
+                for (int k0 = 0; k0 < npass; k0 += 16) {
+                    const int k = k0 + l16;
+                    v4f pa_v = { 0, 0, 0, 0 }, pc_v = { 0, 0, 0, 0 };
+                    const bool ha = k < na, hc = k < nn;
+                    if (ha) pa_v = map[gsa + k];
+                    if (hc) pc_v = map[gsc + k];
+                    const bool ia = ha && pa_v.x >= fx0 && pa_v.x <= fx1 && pa_v.y >= fy0 && pa_v.y <= fy1 && pa_v.z >= fz0 && pa_v.z <= fz1;
+                    const bool ic = hc && pc_v.x >= fx0 && pc_v.x <= fx1 && pc_v.y >= fy0 && pc_v.y <= fy1 && pc_v.z >= fz0 && pc_v.z <= fz1;
+                    const unsigned long long ma = __ballot(ia), mc = __ballot(ic);
+                    const int ca_n = __popcll(ma), cc_n = __popcll(mc);
+                    if (nt + ca_n + cc_n > kTilePts) { overflow = true; break; }
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (ia) lpts[nt + __popcll(ma & below)] = pa_v;
+                    if (ic) lpts[nt + ca_n + __popcll(mc & below)] = pc_v;
+                    nt += ca_n + cc_n;
+                }
             }
             wave_lds_sync();
             S2M_LAP(t_stage);
-            // ---- sweep: every lane, every tile point
-            if (!(ablate & 1)) {
-                int j = 0;
-                for (; j + 4 <= ptot; j += 4) {
-                    const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                    consider(best, worst, m0, sx, sy, sz);
-                    consider(best, worst, m1, sx, sy, sz);
-                    consider(best, worst, m2, sx, sy, sz);
-                    consider(best, worst, m3, sx, sy, sz);
+            if (!overflow) {
+                if (HOOK) { dbg_mode = 1; dbg_pts = nt; }
+                // ---- sweep: every lane, every tile point
+                if (!(ablate & 1)) {
+                    int j = 0;
+                    for (; j + 4 <= nt; j += 4) {
+                        const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                        consider(best, bound, gatef, m0, sx, sy, sz);
+                        consider(best, bound, gatef, m1, sx, sy, sz);
+                        consider(best, bound, gatef, m2, sx, sy, sz);
+                        consider(best, bound, gatef, m3, sx, sy, sz);
+                    }
+                    for (; j < nt; j++) consider(best, bound, gatef, lpts[j], sx, sy, sz);
                 }
-                for (; j < ptot; j++) consider(best, worst, lpts[j], sx, sy, sz);
-            }
-            S2M_LAP(t_search);
-        } else {
+                S2M_LAP(t_search);
+            } else { tile = false; if (HOOK) dbg_why = 3; }   // too many survivors: gather instead
+        }
+        if (!tile) {
             if (HOOK) dbg_mode = 2;
-            // ---- gather: run bounds of all 9 rows first (independent loads), then the runs
-            int32_t (*lrun)[64] = s_run[wave];
-            if (valid) {
+            // ---- gather: run bounds of all 9 rows first (independent loads), then two points of
+            // every live run per batch
+            if (fin && !(ablate & 1)) {
                 int rs[9], re[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
@@ -710,51 +757,47 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                     const int yy = cy + dyc, zz = cz + dzc;
                     const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
                     rs[k] = 0; re[k] = 0;
-                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > worst)) {
-                        const int xs = (x0 < cx && lb + gx2m <= worst) ? x0 : cx;     // left cell still reachable?
-                        const int xe = (x1 > cx && lb + gx2p <= worst) ? x1 : cx;     // right cell?
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > bound)) {
+                        const int xs = (x0 < cx && lb + gx2m <= bound) ? x0 : cx;     // left cell still reachable?
+                        const int xe = (x1 > cx && lb + gx2p <= bound) ? x1 : cx;     // right cell?
                         const int rb = (zz * g.ny + yy) * g.nx;
                         rs[k] = cell_start[rb + xs];
                         re[k] = cell_start[rb + xe + 1];
                     }
                 }
-#pragma unroll
-                for (int k = 0; k < 9; k++) { lrun[2 * k][lane] = rs[k]; lrun[2 * k + 1][lane] = re[k]; }
-            }
-            wave_lds_sync();
-            S2M_LAP(t_stage);
-            if (valid && !(ablate & 1)) {
-                // software pipeline: the first 4 points of run k+1 are in flight while run k is
-                // processed (past a run's end its last point is re-read: a dup, rejected for free)
-                int jn = lrun[0][lane], en = lrun[1][lane];
+                // software pipeline over the runs: the first 4 points of run k+1 are in flight while
+                // run k is processed (past a run's end its last point is re-read: a dup, rejected for free)
                 v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
-                if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-#pragma unroll 1
+                if (rs[0] < re[0]) { n0 = map[rs[0]]; n1 = map[min(rs[0] + 1, re[0] - 1)]; n2 = map[min(rs[0] + 2, re[0] - 1)]; n3 = map[min(rs[0] + 3, re[0] - 1)]; }
+#pragma unroll
                 for (int k = 0; k < 9; k++) {
-                    int j = jn; const int e = en;
                     const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
                     if (k < 8) {
-                        jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
-                        if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+                        if (rs[k + 1] < re[k + 1]) {
+                            const int jn = rs[k + 1], en = re[k + 1];
+                            n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)];
+                        }
                     }
-                    if (j >= e) continue;
                     const int dyc = run_dy(k), dzc = run_dz(k);
                     const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                    if (lb > worst) continue;                                          // bound tightened meanwhile
-                    if (HOOK) dbg_pts += e - j;
-                    consider(best, worst, m0, sx, sy, sz);
-                    consider(best, worst, m1, sx, sy, sz);
-                    consider(best, worst, m2, sx, sy, sz);
-                    consider(best, worst, m3, sx, sy, sz);
-                    for (j += 4; j < e; j += 4) {   // long runs: 4 loads in flight
-                        const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
-                        consider(best, worst, q0, sx, sy, sz);
-                        consider(best, worst, q1, sx, sy, sz);
-                        consider(best, worst, q2, sx, sy, sz);
-                        consider(best, worst, q3, sx, sy, sz);
+                    if (rs[k] < re[k] && !(lb > bound)) {                              // bound may have tightened meanwhile
+                        if (HOOK) dbg_pts += re[k] - rs[k];
+                        consider(best, bound, gatef, m0, sx, sy, sz);
+                        consider(best, bound, gatef, m1, sx, sy, sz);
+                        consider(best, bound, gatef, m2, sx, sy, sz);
+                        consider(best, bound, gatef, m3, sx, sy, sz);
+                        for (int j = rs[k] + 4; j < re[k]; j += 4) {                   // long runs: 4 loads in flight
+                            const int e = re[k];
+                            const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
+                            consider(best, bound, gatef, q0, sx, sy, sz);
+                            consider(best, bound, gatef, q1, sx, sy, sz);
+                            consider(best, bound, gatef, q2, sx, sy, sz);
+                            consider(best, bound, gatef, q3, sx, sy, sz);
+                        }
                     }
                 }
             }
+            S2M_LAP(t_stage);
             S2M_LAP(t_search);
         }
     }
@@ -767,20 +810,20 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     if (valid) {
         // this launch's neighbours are the next launch's prior (only a complete set is usable)
         const bool full = best.key[4] != kKeyInf;
-        uint32_t nidx[5];
         bool same = full;
 #pragma unroll
-        for (int j = 0; j < 5; j++) {
-            nidx[j] = (uint32_t)(best.key[j] & 0xffffffffu);
-            same = same && ((int32_t)nidx[j] == pidx[j]);
-        }
+        for (int j = 0; j < 5; j++) same = same && ((int32_t)(uint32_t)(best.key[j] & 0xffffffffu) == pidx[j]);
         if (!same) {
 #pragma unroll
-            for (int j = 0; j < 5; j++) prev5[(size_t)j * nq + i] = full ? (int32_t)nidx[j] : -1;
+            for (int j = 0; j < 5; j++) {
+                const v4f o = { best.x[j], best.y[j], best.z[j], __int_as_float(full ? (int32_t)(uint32_t)(best.key[j] & 0xffffffffu) : -1) };
+                prevp[(size_t)j * nq + i] = o;
+            }
         }
 
         const float d2_4 = __uint_as_float((uint32_t)(best.key[4] >> 32));
-        const bool gated = ((double)d2_4 < cp->gate_sq) && !(ablate & 2);           // :1097
+        const bool near5 = (double)d2_4 < cp->gate_sq;                              // :1097
+        const bool gated = near5 && !(ablate & 2);
         bool keep = false;
         float cf[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (gated) {
@@ -795,13 +838,9 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                 const v4f pl = pcache[i];
                 pa = pl.x; pb = pl.y; pc = pl.z; pd = pl.w; planeValid = (pst == 1);
             } else {
-                float qr[5][3], nb[5][3];
+                float qr[5][3];
 #pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const v4f m = mo[nidx[j]];
-                    qr[j][0] = m.x; qr[j][1] = m.y; qr[j][2] = m.z;                  // :1099-1101
-                    nb[j][0] = m.x; nb[j][1] = m.y; nb[j][2] = m.z;
-                }
+                for (int j = 0; j < 5; j++) { qr[j][0] = best.x[j]; qr[j][1] = best.y[j]; qr[j][2] = best.z[j]; }   // :1099-1101
                 float X[3];
                 plane_fit_5x3(qr, X);                                                // :1104
                 pa = X[0]; pb = X[1]; pc = X[2]; pd = 1.0f;
@@ -810,7 +849,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                 planeValid = true;
 #pragma unroll
                 for (int j = 0; j < 5; j++) {                                        // :1115-1122
-                    const float r = pa * nb[j][0] + pb * nb[j][1] + pc * nb[j][2] + pd;
+                    const float r = pa * best.x[j] + pb * best.y[j] + pc * best.z[j] + pd;
                     if ((double)fabsf(r) > cp->plane_tol) planeValid = false;
                 }
                 const v4f pl = { pa, pb, pc, pd };
@@ -862,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         }
     }
 
-    if (HOOK) clk2 = wall_clock64();
+    if (HOOK) { if (dbg_mode != 1) dbg_skip = wave_max_i32((dbg_mode == 2) ? dbg_pts : 0); clk2 = wall_clock64(); }
     // ---- wave reduction by recursive halving: at mask m a lane keeps one half of its sums and
     // hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
     // five steps lane l holds, in acc[0], sum number l>>1 over its half-wave pair group, and one
@@ -883,8 +922,8 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     if (HOOK && cp->dbg_clk && lane == 0) {
         const auto d = G(cp->dbg_clk) + 16 * ((size_t)blockIdx.x * NW + wave);
         d[0] = tk_start; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
-        d[4] = (unsigned long long)dbg_mode; d[5] = (unsigned long long)dbg_rows; d[6] = (unsigned long long)dbg_pts; d[7] = 0;
-        d[8] = t_bbox; d[9] = t_mark; d[10] = 0; d[11] = t_stage; d[12] = t_search; d[13] = 0; d[14] = 0; d[15] = 0;
+        d[4] = (unsigned long long)dbg_mode; d[5] = (unsigned long long)dbg_rows; d[6] = (unsigned long long)dbg_pts; d[7] = (unsigned long long)dbg_raw;
+        d[8] = t_bbox; d[9] = t_mark; d[10] = 0; d[11] = t_stage; d[12] = t_search; d[13] = (unsigned long long)dbg_why; d[14] = (unsigned long long)dbg_box; d[15] = (unsigned long long)dbg_skip;
     }
     __syncthreads();
     if (tid < kAcc) {

@@ -8,6 +8,7 @@
 namespace s2m {
 
 constexpr int kBlock = 256;            // threads per workgroup of the registration kernel (4 waves)
+constexpr int kWaveQ = 64;             // scan points per wave (<= 64; fewer = tighter boxes, more waves)
 constexpr int kAcc = 28;               // 21 upper-triangular JtJ + 6 Jtr + 1 correspondence count
 constexpr int kFinThreads = 512;       // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
@@ -44,11 +45,10 @@ struct DevState {
 struct DevCtx {
     GridDesc g;
     const float4* map_sorted;     // [n_m] x,y,z, original index (bit pattern), cell-sorted
-    const float4* map_orig;       // [n_m] x,y,z in the caller's order
     const int32_t* cell_start;    // [ncells+1]
     const float* qx; const float* qy; const float* qz;   // [n_q] lidar-frame scan, SoA, locality-sorted
     const int32_t* qperm;         // [n_q] sorted position -> original scan index
-    int32_t* prev5;               // [5][n_q] previous launch's neighbours per sorted scan point, -1 = none
+    float4*  prevp;               // [5][n_q] previous launch's neighbours per sorted scan point: x,y,z, map index (-1 = none)
     float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to prev5's tuple
     int32_t* plane_state;         // [n_q] 0 none, 1 plane passed the inlier test, 2 plane failed it
     int32_t n_q, n_m, nblocks;
@@ -56,6 +56,7 @@ struct DevCtx {
     DevState* state;
     s2m_iter_trace* trace;        // [kMaxIter]
     // parameters
+    float  gate_f;                // smallest fp32 >= gate_sq: nothing at or beyond it is observable
     double gate_sq, plane_tol, weight_scale, weight_min, conv_deg, conv_cm;
     float  eig_thresh;
     int32_t min_corr, max_iter, early_exit;

@@ -252,7 +252,7 @@ class MapOptimizationS2M:
     def wave_profile(self, pose) -> np.ndarray:
         """Diagnostics: (n_waves, 16) uint64 per-wave stamps/stats of one k_register pass."""
         p = np.ascontiguousarray(pose, np.float32)
-        cap = (self.laserCloudSurfLastDSNum + 63) // 64 + 64
+        cap = (self.laserCloudSurfLastDSNum + 15) // 16 + 256
         out = np.zeros((cap, 16), np.uint64)
         n = self.lib.s2m_debug_wave_profile(self.h, _fp(p), out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
         if n < 0:

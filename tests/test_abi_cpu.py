@@ -68,3 +68,18 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):
                 src = open(os.path.join(root, f)).read()
                 assert not pat.search(src), f"{f} reaches into the oracle"
+
+
+def test_cpp_host_harness_builds_and_fails_loudly_without_gpu():
+    """The C++ host mirror (liorf_amd/host) links against the C ABI; without a GPU it must refuse."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "liorf_amd", "host", "s2m_harness")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "liorf_amd", "host")])
+    out = subprocess.run([exe, "--version"], capture_output=True, text=True)
+    assert out.returncode == 0 and "gfx950" in out.stdout
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    out = subprocess.run([exe, "m.bin", "s.bin", "0", "0", "0", "0", "0", "0"], capture_output=True, text=True)
+    assert out.returncode == 1 and "no CPU fallback" in out.stderr

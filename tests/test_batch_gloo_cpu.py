@@ -1,0 +1,68 @@
+"""N > 1 path on CPU: two gloo ranks shard a batch of scans and all-gather the pose records
+(the same code path bench.py / a multi-GPU caller drives with backend "nccl" = RCCL)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from liorf_amd import batch
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_scans, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        mine = batch.shard_scans(n_scans, world, rank)
+        # stand-in results: what scan2MapOptimization would return for scan s (no GPU here)
+        recs = np.stack([batch.pack_record([0.01 * s, -0.02 * s, 0.3 + s, 1.5 + s, -0.7, 0.1], 5 + s, 1000 * s)
+                         for s in mine]) if mine else np.zeros((0, 8), np.float32)
+        table = batch.gather_records(recs, n_scans)
+        q.put((rank, table))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_scans", [8, 5, 1])
+def test_two_ranks_gather_all_poses(n_scans):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_scans, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tables = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    expect = np.stack([batch.pack_record([0.01 * s, -0.02 * s, 0.3 + s, 1.5 + s, -0.7, 0.1], 5 + s, 1000 * s)
+                       for s in range(n_scans)])
+    for r in range(world):
+        assert np.array_equal(tables[r], expect)
+
+
+def test_shard_is_a_partition():
+    for n in (0, 1, 7, 8, 33):
+        for world in (1, 2, 4, 8):
+            parts = [batch.shard_scans(n, world, r) for r in range(world)]
+            flat = sorted(i for p in parts for i in p)
+            assert flat == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def test_single_process_path_needs_no_group():
+    recs = np.stack([batch.pack_record(np.arange(6) + s, s, s) for s in range(3)])
+    assert np.array_equal(batch.gather_records(recs, 3), recs)

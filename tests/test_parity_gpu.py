@@ -191,3 +191,28 @@ def test_scancontext_descriptor(gpu, cfg_small):
     assert (desc != odesc).sum() <= 2
     same = desc == odesc
     assert np.allclose(key[same.all(axis=1)], okey[same.all(axis=1)], rtol=0, atol=1e-12)
+
+
+def test_cpp_host_mirror_matches_oracle(tmp_path, cfg_tiny):
+    """The C++ MapOptimizationS2M (liorf_amd/host) on PointXYZI records, end to end."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "liorf_amd", "host", "s2m_harness")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(root, "liorf_amd", "host")])
+    m, s = synth.to_xyzi(cfg_tiny["map"]), synth.to_xyzi(cfg_tiny["scan"])
+    (tmp_path / "m.bin").write_bytes(m.tobytes())
+    (tmp_path / "s.bin").write_bytes(s.tobytes())
+    pose = cfg_tiny["pose_init"]
+    out = subprocess.run([exe, str(tmp_path / "m.bin"), str(tmp_path / "s.bin")] + ["%.9g" % v for v in pose],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    got = np.array([float(v) for v in lines[1].split()[1:]], np.float32)
+    orc = O.Oracle(knn_backend=1)
+    orc.set_map(m)
+    orc.set_scan(s)
+    ro = orc.scan2MapOptimization(np.array([float("%.9g" % v) for v in pose], np.float32))
+    assert ("iters %d " % ro.iters_run) in lines[0]
+    assert np.abs(got - np.array(ro.pose)).max() <= 1e-4

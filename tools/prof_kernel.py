@@ -21,9 +21,14 @@ if os.environ.get("S2M_WAVES"):
     for name, a in (("stage+search", search), ("plane+jac", plane), ("reduce", red), ("total", tot)):
         print("%-13s med %.2f p90 %.2f p99 %.2f max %.2f us" % (name, np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max()))
     o = np.argsort(-tot)[:8]
-    print("slowest waves: total_us path(1=tile,2=gather) rows pts start_us")
+    o = np.argsort(-tot)[:16]
+    print("slowest waves: total_us path(1=tile,2=gather) rows pts raw why(1 rows,2 raw,3 overflow) box(x,y,z) max_lane_candidates(gather)")
     for i in o:
-        print("   %.2f %d %d %d %.2f" % (tot[i], w[i, 4], w[i, 5], w[i, 6], (w[i, 0] - t0) / 100.0))
+        b = int(w[i, 14])
+        print("   %.2f %d %d %d %d %d (%d,%d,%d) %d" % (tot[i], w[i, 4], w[i, 5], w[i, 6], w[i, 7], w[i, 13], b >> 20, (b >> 10) & 1023, b & 1023, w[i, 15]))
+    for why in (1, 2, 3):
+        sel = (w[:, 4] == 2) & (w[:, 13] == why)
+        if sel.any(): print("gather because %d: %d waves, total med %.2f max %.2f" % (why, sel.sum(), np.median(tot[sel]), tot[sel].max()))
     for name, col in (("box", 8), ("mark", 9), ("rows", 10), ("stage", 11), ("search", 12)):
         a = w[:, col] / 100.0
         print("  %-7s med %.2f p90 %.2f p99 %.2f max %.2f us" % (name, np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max()))
