@@ -161,9 +161,11 @@ int  s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6
 /* Raw device time (ms) of the last s2m_optimize* call, measured with HIP events
  * on the handle's stream; and of the last s2m_set_map / s2m_set_scan index build. */
 int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float* set_scan_ms);
-/* Benchmark helper: runs `reps` back-to-back launches of the per-iteration
- * registration kernel (kNN + plane + Jacobian + block reduction) at `pose`
- * between two HIP events on the handle's stream; returns mean ms per launch. */
+/* Benchmark helper: runs `reps` complete LM loops (max_iter iterations, early exit as
+ * configured, each loop starting like a fresh scan) on the resident scan + map with plain
+ * launches and a HIP-event pair on the handle's stream around every launch of the
+ * per-iteration registration kernel (k_register: kNN + plane + Jacobian + block reduction);
+ * returns the mean duration of those launches in ms. */
 int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float* ms_per_launch);
 
 /* Diagnostics: one k_register pass at `pose`; per wave (64 locality-sorted scan points) 16 words:

@@ -15,6 +15,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "s2m_host_math.hpp"
 #include "s2m_kernels.hpp"
@@ -44,7 +45,7 @@ struct s2m_context {
     // map side
     DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
     // scan side
-    DevBuf raw_scan, qx, qy, qz, qperm, prevp, plane_cache, plane_state, q_counts, q_cell_start, q_cell_of, q_rank_of;
+    DevBuf raw_scan, qx, qy, qz, qperm, prevp, plane_cache, plane_state, chunk_parts, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
 
@@ -65,6 +66,7 @@ struct s2m_context {
     float persist_matP[36] = { 0 };
 
     std::map<int, hipGraphExec_t> graphs;
+    std::vector<hipEvent_t> iter_events;
     bool use_graph = true;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
     float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
@@ -234,8 +236,9 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
     h->n_q = n; h->have_scan = true;
     h->hctx.n_q = (int32_t)n;
-    constexpr int per_block = kWaveQ * (kBlock / 64);
-    int nblocks = (int)((n + per_block - 1) / per_block);
+    // wave table capacity: every 64-point chunk plus a 50 % budget of extra waves for split chunks
+    const int n_chunks = (int)((n + 63) / 64);
+    int nblocks = (n_chunks + n_chunks / 2 + 3) / 4;
     nblocks = ((nblocks + kBlocksQuantum - 1) / kBlocksQuantum) * kBlocksQuantum;
     if (nblocks == 0) nblocks = kBlocksQuantum;
     h->hctx.nblocks = nblocks;
@@ -280,6 +283,19 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
 
     h->hctx.qx = h->qx.as<float>(); h->hctx.qy = h->qy.as<float>(); h->hctx.qz = h->qz.as<float>();
     h->hctx.qperm = h->qperm.as<int32_t>();
+    {
+        const int capacity = h->hctx.nblocks * (kBlock / 64);
+        if ((rc = ensure(h, h->chunk_parts, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
+        if ((rc = ensure(h, h->wave_table, sizeof(int2) * (size_t)capacity))) return rc;
+        if ((rc = ensure(h, h->n_waves, 64))) return rc;
+        hipLaunchKernelGGL(k_chunk_parts, dim3((n_chunks + 3) / 4), dim3(256), 0, h->stream, (const float*)h->qx.as<float>(),
+                           (const float*)h->qy.as<float>(), (const float*)h->qz.as<float>(), (int)n, n_chunks, h->chunk_parts.as<int32_t>());
+        hipLaunchKernelGGL(k_chunk_table, dim3(1), dim3(1024), 0, h->stream, (const int32_t*)h->chunk_parts.as<int32_t>(), (int)n, n_chunks,
+                           capacity, h->wave_table.as<int2>(), h->n_waves.as<int32_t>());
+        S2M_HIP(h, hipGetLastError());
+        h->hctx.wave_table = h->wave_table.as<int2>();
+        h->hctx.n_waves = h->n_waves.as<int32_t>();
+    }
     h->hctx.prevp = h->prevp.as<float4>();
     h->hctx.plane_cache = h->plane_cache.as<float4>();
     h->hctx.plane_state = h->plane_state.as<int32_t>();
@@ -442,8 +458,9 @@ int s2m_destroy(s2m_handle h)
     hipSetDevice(h->device);
     if (h->stream) hipStreamSynchronize(h->stream);
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
+    for (hipEvent_t e : h->iter_events) hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
-                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->plane_cache, &h->plane_state, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->plane_cache, &h->plane_state, &h->chunk_parts, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out };
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
@@ -662,17 +679,36 @@ int s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float
     S2M_HIP(h, hipSetDevice(h->device));
     int rc;
     if ((rc = upload_ctx(h))) return rc;
-    if ((rc = push_state(h, pose))) return rc;
     const DevCtx* dc = h->dctx.as<DevCtx>();
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
-    S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
-    S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
-    S2M_HIP(h, hipGetLastError());
-    S2M_HIP(h, hipStreamSynchronize(h->stream));
-    float ms = 0;
-    S2M_HIP(h, hipEventElapsedTime(&ms, h->ev_a, h->ev_b));
-    *ms_per_launch = ms / (float)reps;
+    const int nit = h->prm.max_iter;
+    if (h->iter_events.size() < (size_t)(2 * nit)) {
+        const size_t old = h->iter_events.size();
+        h->iter_events.resize(2 * nit);
+        for (size_t k = old; k < h->iter_events.size(); k++) S2M_HIP(h, hipEventCreate(&h->iter_events[k]));
+    }
+    double total_ms = 0.0;
+    long launches = 0;
+    for (int rep = 0; rep < reps; rep++) {
+        // a new scan starts without a prior or cached planes (what s2m_set_scan leaves behind)
+        S2M_HIP(h, hipMemsetAsync(h->prevp.p, 0xff, sizeof(float4) * 5 * h->n_q, h->stream));
+        S2M_HIP(h, hipMemsetAsync(h->plane_state.p, 0, sizeof(int32_t) * h->n_q, h->stream));
+        if ((rc = push_state(h, pose))) return rc;
+        for (int it = 0; it < nit; it++) {          // the real loop, launched one by one between event pairs
+            S2M_HIP(h, hipEventRecord(h->iter_events[2 * it], h->stream));
+            hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
+            S2M_HIP(h, hipEventRecord(h->iter_events[2 * it + 1], h->stream));
+            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, it, 0);
+        }
+        S2M_HIP(h, hipGetLastError());
+        S2M_HIP(h, hipStreamSynchronize(h->stream));
+        const int ran = std::min(nit, std::max(1, (int)0x7fffffff));
+        for (int it = 0; it < ran; it++) {
+            float ms = 0;
+            S2M_HIP(h, hipEventElapsedTime(&ms, h->iter_events[2 * it], h->iter_events[2 * it + 1]));
+            total_ms += ms; launches++;
+        }
+    }
+    *ms_per_launch = (float)(total_ms / (double)launches);
     return S2M_OK;
 }
 

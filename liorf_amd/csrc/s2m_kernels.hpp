@@ -278,6 +278,93 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
     qx[pos] = p[0]; qy[pos] = p[1]; qz[pos] = p[2]; qperm[pos] = i;
 }
 
+// Work-proportional wave assignment.  The sorted scan is cut into chunks of 64 points; a chunk
+// whose points spread over a large box (sparse far field, tall structures) would make its wave
+// stage and sweep a large map tile, and the slowest wave sets the kernel time.  Such chunks are
+// given to 2 or 4 waves (32 / 16 points each: tighter boxes, run in parallel).  The extent is
+// measured in the lidar frame - a rigid transform does not change it.
+__global__ __launch_bounds__(256) void k_chunk_parts(const float* __restrict__ qx, const float* __restrict__ qy,
+                                                     const float* __restrict__ qz, int n, int n_chunks,
+                                                     int32_t* __restrict__ parts)
+{
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n_chunks) return;
+    const int i = c * 64 + lane;
+    const bool v = i < n;
+    const float x = v ? qx[i] : 0.0f, y = v ? qy[i] : 0.0f, z = v ? qz[i] : 0.0f;
+    const bool f = v && fabsf(x) < 3.0e38f && fabsf(y) < 3.0e38f && fabsf(z) < 3.0e38f;
+    float mn[3] = { f ? x : INFINITY, f ? y : INFINITY, f ? z : INFINITY };
+    float mx[3] = { f ? x : -INFINITY, f ? y : -INFINITY, f ? z : -INFINITY };
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64));
+            mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64));
+        }
+    }
+    if (lane == 0) {
+        int p = 1;
+        if (mn[0] <= mx[0]) {
+            // cells a wave's box would span (1 m cells, +1 halo each side, bound radius)
+            const float vol = (mx[0] - mn[0] + 3.0f) * (mx[1] - mn[1] + 3.0f) * (mx[2] - mn[2] + 3.0f);
+            p = vol > 700.0f ? 4 : (vol > 180.0f ? 2 : 1);
+        }
+        parts[c] = p;
+    }
+}
+
+// one workgroup: exclusive scan of parts[] and emission of the wave table {first point, count}.
+// The table has room for every chunk unsplit plus a budget of extra waves; if the wishes exceed
+// it they are scaled back uniformly (4 -> 2, then everything -> 1), so the table never overflows.
+__global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict__ parts, int n, int n_chunks, int capacity,
+                                                      int2* __restrict__ table, int32_t* __restrict__ n_waves_out)
+{
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry_s, tot_s[2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // pass A: total waves wished for, at full wishes and with 4 -> 2
+    int t0 = 0, t1 = 0;
+    for (int c = threadIdx.x; c < n_chunks; c += 1024) { const int p = parts[c]; t0 += p; t1 += min(p, 2); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { t0 += __shfl_xor(t0, off, 64); t1 += __shfl_xor(t1, off, 64); }
+    if (threadIdx.x == 0) { carry_s = 0; tot_s[0] = 0; tot_s[1] = 0; }
+    __syncthreads();
+    if (lane == 0) { atomicAdd(&tot_s[0], t0); atomicAdd(&tot_s[1], t1); }
+    __syncthreads();
+    const int level = (tot_s[0] <= capacity) ? 0 : ((tot_s[1] <= capacity) ? 1 : 2);
+    // pass B: scan and emit
+    for (int base = 0; base < n_chunks; base += 1024) {
+        const int c = base + threadIdx.x;
+        int p = (c < n_chunks) ? parts[c] : 0;
+        if (level == 1) p = min(p, 2); else if (level == 2) p = min(p, 1);
+        int incl = p;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; w++) woff += wsum[w];
+        const int carry = carry_s;
+        const int off0 = carry + woff + incl - p;            // first wave slot of chunk c
+        if (c < n_chunks) {
+            const int per = 64 / p;
+            for (int j = 0; j < p; j++) {
+                const int start = c * 64 + j * per;
+                if (off0 + j < capacity) table[off0 + j] = make_int2(start, max(0, min(per, n - start)));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = carry + woff + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *n_waves_out = min(carry_s, capacity);
+}
+
 // ------------------------------------------------------------------------------------------
 // per-correspondence arithmetic
 // ------------------------------------------------------------------------------------------
@@ -456,9 +543,10 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // No barrier is needed until the final reduction: a wave only reads LDS it wrote itself.
 // combineOptimizationCoeffs() (:1145-1156) has no counterpart: rejected lanes contribute zeros.
 // ------------------------------------------------------------------------------------------
-constexpr int kTilePts = 128;        // points per wave tile (2 KiB) after filtering
-constexpr int kTileRaw = 640;        // unfiltered points a wave is willing to stream through the filter
-constexpr int kRowLoop = 48;         // boxes up to this many rows are candidates for the tile path
+constexpr int kTilePts = 448;        // points per wave tile (7 KiB) after filtering
+constexpr int kTilePtsCold = 128;    // largest tile a lane sweeps with the full insertion test; beyond it that lane gathers
+constexpr int kTileRaw = 704;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
+constexpr int kRowMax = 256;         // boxes with more rows go straight to the gather path
 constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning (<= 5e-5)
 constexpr uint64_t kKeyInf = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu;
 
@@ -582,12 +670,15 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     __shared__ double red[NW][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // wave w of workgroup b takes chunk w*gridDim.x + b of 64 sorted points: neighbouring chunks
+    // wave w of workgroup b takes entry w*gridDim.x + b of the wave table: neighbouring chunks
     // (similar cost: the sort runs from the dense near field to the sparse far field) land on
     // different CUs, which evens out both the work and the L2-miss queues
-    const int i = (wave * (int)gridDim.x + (int)blockIdx.x) * kWaveQ + lane;
+    const int wg = wave * (int)gridDim.x + (int)blockIdx.x;
+    int2 chunk = make_int2(0, 0);
+    if (wg < *G(cp->n_waves)) { const auto tb = G((const int2*)cp->wave_table); chunk.x = tb[wg].x; chunk.y = tb[wg].y; }
+    const int i = chunk.x + lane;
     const int nq = cp->n_q;
-    const bool valid = lane < kWaveQ && i < nq;
+    const bool valid = lane < chunk.y && i < nq;
     v4f* lpts = s_pts[wave];
 
     const GridDesc g = cp->g;
@@ -637,6 +728,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     const float mnz = wave_min_f32(fin ? sz : INFINITY), mxz = wave_max_f32(fin ? sz : -INFINITY);
     const float rmax2 = wave_max_f32(fin ? bound : 0.0f);
 
+    bool certain_far = false;                             // proved: fewer than 5 map points inside the gate
     unsigned long long clk1 = 0, clk2 = 0;
     int dbg_mode = 0, dbg_rows = 0, dbg_pts = 0, dbg_raw = 0, dbg_why = 0, dbg_box = 0, dbg_skip = 0;
     S2M_LAP(t_bbox);
@@ -652,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
         const int R = nyb * nzb;                          // rows in the box
         const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);      // this lane's cells in a row
-        if (HOOK) { dbg_rows = R; dbg_box = ((bx1 - bx0 + 1) << 20) | (nyb << 10) | nzb; dbg_why = (R > kRowLoop) ? 1 : 0; }
+        if (HOOK) { dbg_rows = R; dbg_box = ((bx1 - bx0 + 1) << 20) | (nyb << 10) | nzb; dbg_why = 0; }
 
         // squared slab distances of this query to the faces of its own cell: lower bounds of the
         // distance to anything in the neighbouring row / cell on that side (see kSlabMargin)
@@ -665,10 +757,18 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         const float gy2m = gym * gym * 0.9999f, gy2p = gyp * gyp * 0.9999f;
         const float gz2m = gzm * gzm * 0.9999f, gz2p = gzp * gzp * 0.9999f;
 
-        // ---- tile path? mark the box rows some lane still needs, size them, decide
-        bool tile = false;
-        int gs = 0, len = 0, ptot = 0;                    // lane r: row r of the box
-        if (R <= kRowLoop && !(ablate & 64)) {
+        // ---- tile path: per group of 64 box rows, mark the rows some lane still needs, size them
+        // and stream them through the filter into the tile; gather only if the tile overflows
+        // a box far larger than the lanes' own neighbourhoods (scattered points) is not worth staging
+        const int nfin = __popcll(__ballot(fin));
+        const int tile_cap = kTilePts;
+        const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
+        const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
+        bool glanes = false;                              // lanes that take the gather path
+        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 40 * nfin;
+        if (HOOK && !tile) dbg_why = 1;
+        int nt = 0;                                       // tile fill (wave-uniform)
+        for (int rg = 0; rg < R && tile; rg += 64) {
             // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
             unsigned long long need = 0ull;
             if (fin) {
@@ -677,38 +777,34 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                     const int dyc = run_dy(k), dzc = run_dz(k);
                     const int yy = cy + dyc, zz = cz + dzc;
                     const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > bound))
-                        need |= 1ull << ((zz - bz0) * nyb + (yy - by0));
+                    const int r = (zz - bz0) * nyb + (yy - by0) - rg;
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > bound) && r >= 0 && r < 64)
+                        need |= 1ull << r;
                 }
             }
             const uint32_t nlo = wave_or_u32((uint32_t)need), nhi = wave_or_u32((uint32_t)(need >> 32));
             const bool mine = (((lane < 32) ? (nlo >> lane) : (nhi >> (lane - 32))) & 1u) != 0u;
+            int gs = 0, len = 0;                          // lane r: row rg + r of the box
             if (mine) {                                   // whole rows: a compact wave's box is narrow in x
-                const int zq = lane / nyb;
-                const int gcell = ((bz0 + zq) * g.ny + by0 + (lane - zq * nyb)) * g.nx;
+                const int r = rg + lane;
+                const int zq = r / nyb;
+                const int gcell = ((bz0 + zq) * g.ny + by0 + (r - zq * nyb)) * g.nx;
                 gs = cell_start[gcell + bx0];
                 len = cell_start[gcell + bx1 + 1] - gs;
             }
-            ptot = __builtin_amdgcn_readlane(wave_incl_scan_i32(len), 63);
-            tile = ptot <= kTileRaw;
-            if (HOOK) { dbg_raw = ptot; if (!tile) dbg_why = 2; }
-        }
-        S2M_LAP(t_mark);
-
-        if (tile) {
+            const int ptot = __builtin_amdgcn_readlane(wave_incl_scan_i32(len), 63);
+            if (HOOK) dbg_raw += ptot;
+            if (ptot > kTileRaw) { tile = false; if (HOOK) dbg_why = 2; break; }
+            S2M_LAP(t_mark);
             // ---- stage through the filter: 16 lanes per row, 8 rows in flight per pass; a point
             // enters the tile only if it lies inside the wave's point box grown by the largest bound
-            const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
-            const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
             const int sub = lane >> 4, l16 = lane & 15;
-            int nt = 0;                                   // tile fill (wave-uniform)
-            bool overflow = false;
-            for (int cb = 0; cb < R && !overflow; cb += 8) {
-                const int ca = cb + sub, cc = cb + 4 + sub;              // < 64: R <= kRowLoop
+            const int nr = min(64, R - rg);
+            for (int cb = 0; cb < nr && tile; cb += 8) {
+                const int ca = cb + sub, cc = min(cb + 4 + sub, 63);
                 const int gsa = __shfl(gs, ca, 64), na = __shfl(len, ca, 64);
-                const int gsc = __shfl(gs, cc, 64), nn = __shfl(len, cc, 64);
-                const int nmax = max(na, nn);
-                const int npass = wave_max_i32(nmax);
+                const int gsc = __shfl(gs, cc, 64), nn = (cb + 4 + sub < 64) ? __shfl(len, cc, 64) : 0;
+                const int npass = wave_max_i32(max(na, nn));
                 for (int k0 = 0; k0 < npass; k0 += 16) {
                     const int k = k0 + l16;
                     v4f pa_v = { 0, 0, 0, 0 }, pc_v = { 0, 0, 0, 0 };
@@ -719,19 +815,48 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                     const bool ic = hc && pc_v.x >= fx0 && pc_v.x <= fx1 && pc_v.y >= fy0 && pc_v.y <= fy1 && pc_v.z >= fz0 && pc_v.z <= fz1;
                     const unsigned long long ma = __ballot(ia), mc = __ballot(ic);
                     const int ca_n = __popcll(ma), cc_n = __popcll(mc);
-                    if (nt + ca_n + cc_n > kTilePts) { overflow = true; break; }
+                    if (nt + ca_n + cc_n > tile_cap) { tile = false; if (HOOK) dbg_why = 3; break; }
                     const unsigned long long below = (1ull << lane) - 1ull;
                     if (ia) lpts[nt + __popcll(ma & below)] = pa_v;
                     if (ic) lpts[nt + ca_n + __popcll(mc & below)] = pc_v;
                     nt += ca_n + cc_n;
                 }
             }
-            wave_lds_sync();
             S2M_LAP(t_stage);
-            if (!overflow) {
-                if (HOOK) { dbg_mode = 1; dbg_pts = nt; }
-                // ---- sweep: every lane, every tile point
-                if (!(ablate & 1)) {
+        }
+
+        if (tile) {
+            wave_lds_sync();
+            if (HOOK) { dbg_mode = 1; dbg_pts = nt; }
+            // ---- verify: count the tile points with d2 <= bound (branch-free, ~10 VALU a point).
+            //  - complete prior and exactly 5: no OTHER point lies within the prior's 5th distance (all 5
+            //    prior points are in the tile: their rows were marked and they pass the filter), so the
+            //    ordered neighbour set is the prior;
+            //  - bound is the gate and fewer than 5: the point is not gated, whatever its neighbours are.
+            bool todo = fin;                              // lanes that still need the full sweep
+            if (!(ablate & 1)) {
+                const bool prior_ok = fin && best.key[4] != kKeyInf &&
+                                      __uint_as_float((uint32_t)(best.key[4] >> 32)) <= bound;
+                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                int j = 0;
+                for (; j + 4 <= nt; j += 4) {
+                    const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                    float d0, d1, d2v, d3;
+                    make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                    make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                    c0 += (d0 <= bound) ? 1 : 0; c1 += (d1 <= bound) ? 1 : 0;
+                    c2 += (d2v <= bound) ? 1 : 0; c3 += (d3 <= bound) ? 1 : 0;
+                }
+                for (; j < nt; j++) { float d; make_key(lpts[j], sx, sy, sz, d); c0 += (d <= bound) ? 1 : 0; }
+                const int cnt = c0 + c1 + c2 + c3;
+                if (prior_ok && cnt == 5) todo = false;
+                else if (fin && bound >= gatef && cnt < 5) { todo = false; certain_far = true; }
+            }
+            // ---- sweep: lanes with a new, lost or missing neighbour examine every tile point (a big
+            // tile costs more per lane than that lane's own 27 cells: those lanes gather instead)
+            if (!(ablate & 1) && __ballot(todo) && nt > kTilePtsCold) { glanes = todo; todo = false; }
+            if (!(ablate & 1) && __ballot(todo)) {
+                if (todo) {
                     int j = 0;
                     for (; j + 4 <= nt; j += 4) {
                         const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
@@ -742,14 +867,15 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                     }
                     for (; j < nt; j++) consider(best, bound, gatef, lpts[j], sx, sy, sz);
                 }
-                S2M_LAP(t_search);
-            } else { tile = false; if (HOOK) dbg_why = 3; }   // too many survivors: gather instead
+                if (HOOK) dbg_skip = __popcll(__ballot(todo));
+            }
+            S2M_LAP(t_search);
         }
-        if (!tile) {
-            if (HOOK) dbg_mode = 2;
-            // ---- gather: run bounds of all 9 rows first (independent loads), then two points of
-            // every live run per batch
-            if (fin && !(ablate & 1)) {
+        if (!tile) glanes = fin;
+        if (__ballot(glanes)) {
+            if (HOOK) dbg_mode = tile ? 3 : 2;
+            // ---- gather: run bounds of all 9 rows first (independent loads), then the runs
+            if (glanes && !(ablate & 1)) {
                 int rs[9], re[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
@@ -823,7 +949,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
 
         const float d2_4 = __uint_as_float((uint32_t)(best.key[4] >> 32));
         const bool near5 = (double)d2_4 < cp->gate_sq;                              // :1097
-        const bool gated = near5 && !(ablate & 2);
+        const bool gated = near5 && !certain_far && !(ablate & 2);
         bool keep = false;
         float cf[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
         if (gated) {
@@ -901,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         }
     }
 
-    if (HOOK) { if (dbg_mode != 1) dbg_skip = wave_max_i32((dbg_mode == 2) ? dbg_pts : 0); clk2 = wall_clock64(); }
+    if (HOOK) { if (dbg_mode != 1) dbg_skip = wave_max_i32((dbg_mode >= 2) ? dbg_pts : 0); clk2 = wall_clock64(); }
     // ---- wave reduction by recursive halving: at mask m a lane keeps one half of its sums and
     // hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
     // five steps lane l holds, in acc[0], sum number l>>1 over its half-wave pair group, and one

@@ -8,7 +8,6 @@
 namespace s2m {
 
 constexpr int kBlock = 256;            // threads per workgroup of the registration kernel (4 waves)
-constexpr int kWaveQ = 64;             // scan points per wave (<= 64; fewer = tighter boxes, more waves)
 constexpr int kAcc = 28;               // 21 upper-triangular JtJ + 6 Jtr + 1 correspondence count
 constexpr int kFinThreads = 512;       // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
@@ -52,6 +51,8 @@ struct DevCtx {
     float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to prev5's tuple
     int32_t* plane_state;         // [n_q] 0 none, 1 plane passed the inlier test, 2 plane failed it
     int32_t n_q, n_m, nblocks;
+    const int2* wave_table;       // [nblocks*4] {first sorted point, count <= 64} per wave
+    const int32_t* n_waves;       // entries of wave_table in use
     double* partials;             // [nblocks][kAcc]
     DevState* state;
     s2m_iter_trace* trace;        // [kMaxIter]

@@ -9,8 +9,8 @@ cfg = synth.make_config(name)
 eng = s2m.MapOptimizationS2M(early_exit=0)
 eng.setInputCloud(synth.to_xyzi(cfg["map"]))
 eng.setScan(synth.to_xyzi(cfg["scan"]))
-ms = eng.time_iteration_kernel(cfg["pose_init"], reps)
-print("ablate=%s k_register %.2f us" % (os.environ.get("S2M_ABLATE", "0"), ms * 1e3))
+ms = eng.time_iteration_kernel(cfg["pose_init"], max(1, reps // 30))
+print("ablate=%s k_register %.2f us (mean over full LM loops)" % (os.environ.get("S2M_ABLATE", "0"), ms * 1e3))
 if os.environ.get("S2M_WAVES"):
     w = eng.wave_profile(cfg["pose_init"]).astype(np.int64)
     w = w[w[:, 0] > 0]
@@ -22,17 +22,19 @@ if os.environ.get("S2M_WAVES"):
         print("%-13s med %.2f p90 %.2f p99 %.2f max %.2f us" % (name, np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max()))
     o = np.argsort(-tot)[:8]
     o = np.argsort(-tot)[:16]
-    print("slowest waves: total_us path(1=tile,2=gather) rows pts raw why(1 rows,2 raw,3 overflow) box(x,y,z) max_lane_candidates(gather)")
+    print("slowest waves: total_us path(1=tile,2=gather,3=tile then gather) rows pts raw why(1 rows,2 raw,3 overflow) box(x,y,z) lanes_in_full_sweep(tile)|max_lane_candidates(gather)")
     for i in o:
         b = int(w[i, 14])
         print("   %.2f %d %d %d %d %d (%d,%d,%d) %d" % (tot[i], w[i, 4], w[i, 5], w[i, 6], w[i, 7], w[i, 13], b >> 20, (b >> 10) & 1023, b & 1023, w[i, 15]))
+    tl = w[:, 4] == 1
+    print("tile waves needing the full sweep: %d of %d; lanes in full sweep: %d" % ((w[tl, 15] > 0).sum(), tl.sum(), w[tl, 15].sum()))
     for why in (1, 2, 3):
         sel = (w[:, 4] == 2) & (w[:, 13] == why)
         if sel.any(): print("gather because %d: %d waves, total med %.2f max %.2f" % (why, sel.sum(), np.median(tot[sel]), tot[sel].max()))
     for name, col in (("box", 8), ("mark", 9), ("rows", 10), ("stage", 11), ("search", 12)):
         a = w[:, col] / 100.0
         print("  %-7s med %.2f p90 %.2f p99 %.2f max %.2f us" % (name, np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max()))
-    for mode, nm in ((1, "tile"), (2, "gather")):
+    for mode, nm in ((1, "tile"), (2, "gather"), (3, "tile+gather")):
         sel = w[:, 4] == mode
         if sel.any():
             print("%s waves: %d (%.1f%%) total med %.2f p99 %.2f max %.2f; search med %.2f max %.2f; pts med %d max %d" % (
