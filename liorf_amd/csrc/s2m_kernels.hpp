@@ -1248,6 +1248,114 @@ __device__ __forceinline__ void store_trace(gptr<s2m_iter_trace> dst, const s2m_
     for (int k = 0; k < 6; k++) { dst->delta[k] = tr.delta[k]; dst->pose[k] = tr.pose[k]; }
 }
 
+// cv::solve(matAtA, matAtB, matX, DECOMP_QR) (:1240) spread over 7 lanes of one wave: lane j < 6
+// owns column j of AtA, lane 6 the right-hand side.  Per reflector l: lane l builds the unit vector
+// (the only serial part: two sqrt, 6-l divides), every owner updates its own column, lane 6
+// applies the stored form of the reflector to b.  Each number goes through exactly the
+// operations, in the order, of the single-lane solve6_qr() above.  `sv` is 8 floats of LDS.
+__device__ __forceinline__ bool solve6_qr_lanes(int lane, float (&col)[6], float* sv, float (*sA)[8], float (&x)[6])
+{
+#pragma unroll
+    for (int l = 0; l < 6; l++) {
+        if (lane == l) {
+            float vl[6];
+            float nrm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6 - l; i++) { vl[i] = col[l + i]; nrm += vl[i] * vl[i]; }
+            const float tmpV = vl[0];
+            vl[0] = vl[0] + (vl[0] >= 0.0f ? 1.0f : -1.0f) * sqrtf(nrm);
+            nrm = sqrtf(nrm + vl[0] * vl[0] - tmpV * tmpV);
+#pragma unroll
+            for (int i = 0; i < 6 - l; i++) { vl[i] /= nrm; sv[i] = vl[i]; }
+        }
+        wave_lds_sync();
+        float vl[6];
+#pragma unroll
+        for (int i = 0; i < 6 - l; i++) vl[i] = sv[i];
+        if (lane >= l && lane < 6) {
+            float v = 0.0f;
+#pragma unroll
+            for (int i = l; i < 6; i++) v += vl[i - l] * col[i];
+#pragma unroll
+            for (int i = l; i < 6; i++) col[i] -= 2.0f * vl[i - l] * v;
+            if (lane == l) {
+#pragma unroll
+                for (int i = 1; i < 6 - l; i++) col[l + i] = vl[i] / vl[0];
+            }
+        } else if (lane == 6) {
+            const float hf = vl[0] * vl[0];
+            float u[6];
+            u[0] = 1.0f;
+#pragma unroll
+            for (int i = 1; i < 6 - l; i++) u[i] = vl[i] / vl[0];
+            float v = 0.0f;
+#pragma unroll
+            for (int i = l; i < 6; i++) v += u[i - l] * col[i];
+#pragma unroll
+            for (int i = l; i < 6; i++) col[i] -= 2.0f * u[i - l] * v * hf;
+        }
+        wave_lds_sync();
+    }
+    if (lane < 7) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) sA[i][lane] = col[i];
+    }
+    wave_lds_sync();
+    bool ok = true;
+    float b[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) b[i] = sA[i][6];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+#pragma unroll
+        for (int j = 5; j > i; j--) b[i] -= b[j] * sA[i][j];
+        if (fabsf(sA[i][i]) < FLT_EPSILON * 10.0f) ok = false;
+        b[i] /= sA[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = ok ? b[i] : 0.0f;
+    return ok;
+}
+
+// Is every eigenvalue of the symmetric 6x6 A safely above `thresh`?  Cholesky of A - s*I in
+// fp64 with s = thresh + margin, margin = 1e-5 * trace(A) (far above the fp32 Jacobi's error of a
+// few ulp of the largest eigenvalue, far below any eigenvalue that matters): if it succeeds,
+// cv::eigen would report all six eigenvalues >= thresh and isDegenerate stays false (:1251-1262).
+__device__ bool all_eigen_above(const float* A, float thresh)
+{
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) tr += (double)A[i * 6 + i];
+    if (!(tr > 0.0) || !(tr < 1.0e30)) return false;
+    const double sft = (double)thresh + 1e-5 * tr;
+    double L[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = (double)A[j * 6 + j] - sft;
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+        if (!(d > 1e-9 * tr)) return false;
+        const double dj = sqrt(d);
+        L[j][j] = dj;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = (double)A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+            L[i][j] = v / dj;
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_finalize: second stage of the AtA/AtB reduction (fixed order: bitwise reproducible for a
+// given workgroup partition) and the rest of LMOptimization (:1177-1292): the 6x6 solve, the
+// iteration-0 degeneracy analysis, the pose update and the convergence test.  It leaves the
+// next iteration's transform in DevState, so the 30-iteration loop (:1304-1315) never returns
+// to the host.  The scalar algebra is spread over a few lanes of wave 0 (QR columns, the three
+// sin/cos pairs) while wave 1 settles the degeneracy question.  mode 1 = normal equations only.
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restrict__ cp, int iter, int mode)
 {
     const auto st = G(cp->state);
@@ -1256,21 +1364,22 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
 
     __shared__ double part[kFinThreads / 32][32];
     __shared__ double tot[32];
+    __shared__ float sAtA[36], sAtB[6], sA[6][8], sv[8], sX[8], sPose[8], sSC[8];
     __shared__ float eA[6][6], eV[6][6], eVi[6][6], eV2[6][6], eW[6];
     __shared__ int eR[6], eC[6];
 
     constexpr int NG = kFinThreads / 32;                // row groups
-    const int t = threadIdx.x, col = t & 31, grp = t >> 5;
+    const int t = threadIdx.x, col = t & 31, grp = t >> 5, lane = t & 63, wave = t >> 6;
     double s = 0.0;
     if (col < kAcc) {
         const auto P = G((const double*)cp->partials);
         const int nb = cp->nblocks;
-        for (int b0 = grp; b0 < nb; b0 += 8 * NG) {      // 8 independent loads in flight per lane
-            double v[8];
+        for (int b0 = grp; b0 < nb; b0 += 16 * NG) {    // 16 independent loads in flight per lane
+            double v[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int b = b0 + u * NG; v[u] = (b < nb) ? P[(size_t)b * kAcc + col] : 0.0; }
+            for (int u = 0; u < 16; u++) { const int b = b0 + u * NG; v[u] = (b < nb) ? P[(size_t)b * kAcc + col] : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) s += v[u];
+            for (int u = 0; u < 16; u++) s += v[u];
         }
     }
     part[grp][col] = s;
@@ -1282,93 +1391,121 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
         tot[t] = v;
     }
     __syncthreads();
-    if (t != 0) return;
 
+    // matAtA / matAtB in fp32 (:1184-1186): entry (a, b), a <= b, is sum number a*6 - a(a-1)/2 + (b-a)
     const int n_sel = (int)tot[27];
-    float AtA[36], AtB[6];
-    {
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int b = a; b < 6; b++) { const float v = (float)tot[k++]; AtA[a * 6 + b] = v; AtA[b * 6 + a] = v; }
-#pragma unroll
-        for (int a = 0; a < 6; a++) AtB[a] = (float)tot[21 + a];
+    if (t < 36) {
+        const int a = min(t / 6, t % 6), b = max(t / 6, t % 6);
+        const float v = (float)tot[a * 6 - (a * (a - 1)) / 2 + (b - a)];
+        sAtA[t] = v; st->AtA[t] = v;
+    } else if (t < 42) {
+        const float v = (float)tot[21 + (t - 36)];
+        sAtB[t - 36] = v; st->AtB[t - 36] = v;
     }
-#pragma unroll
-    for (int k = 0; k < 36; k++) st->AtA[k] = AtA[k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) st->AtB[k] = AtB[k];
-    st->n_sel_last = n_sel;
+    if (t == 0) st->n_sel_last = n_sel;
     if (mode == 1) return;
-
-    s2m_iter_trace tr;
-    tr.n_sel = n_sel; tr.stepped = 0; tr.deltaR = 0.0f; tr.deltaT = 0.0f;
-    float pose[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { pose[k] = st->pose[k]; tr.pose[k] = pose[k]; tr.delta[k] = 0.0f; }
+    __syncthreads();
 
     if (n_sel < cp->min_corr) {                         // :1178-1180: false, pose unchanged;
-        st->stalled = 1; st->done = 1;                  // the remaining iterations repeat this no-op
-        st->iters_run = cp->max_iter;
-        store_trace(trace + iter, tr);
+        if (t == 0) {
+            s2m_iter_trace tr;
+            tr.n_sel = n_sel; tr.stepped = 0; tr.deltaR = 0.0f; tr.deltaT = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { tr.pose[k] = st->pose[k]; tr.delta[k] = 0.0f; }
+            st->stalled = 1; st->done = 1;              // the remaining iterations repeat this no-op
+            st->iters_run = cp->max_iter;
+            store_trace(trace + iter, tr);
+        }
         return;
     }
 
-    float X[6];
-    solve6_qr(AtA, AtB, X);                             // :1240
-
-    if (iter == 0) {                                    // :1242-1264
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eA[i][j] = AtA[i * 6 + j];
-        eigen6_sym(eA, eV, eW, eR, eC);
+    // ---- wave 0: the QR solve on 7 lanes.  wave 1 (iteration 0 only): the degeneracy analysis.
+    if (wave == 0) {
+        float colv[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) colv[i] = (lane < 6) ? sAtA[i * 6 + lane] : ((lane == 6) ? sAtB[i] : 0.0f);
+        float X[6];
+        solve6_qr_lanes(lane, colv, sv, sA, X);         // :1240
+        if (lane == 6) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) sX[k] = X[k];
+        }
+    } else if (wave == 1 && lane == 0 && iter == 0) {   // :1242-1264
         int degenerate = 0;
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eV2[i][j] = eV[i][j];
-        for (int i = 5; i >= 0; i--) {
-            if (eW[i] < cp->eig_thresh) { for (int j = 0; j < 6; j++) eV2[i][j] = 0.0f; degenerate = 1; }
-            else break;
+        if (!all_eigen_above(sAtA, cp->eig_thresh)) {
+            // the full restatement: cv::eigen, the row-zeroing loop, matP = matV.inv() * matV2
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eA[i][j] = sAtA[i * 6 + j];
+            eigen6_sym(eA, eV, eW, eR, eC);
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eV2[i][j] = eV[i][j];
+            for (int i = 5; i >= 0; i--) {
+                if (eW[i] < cp->eig_thresh) { for (int j = 0; j < 6; j++) eV2[i][j] = 0.0f; degenerate = 1; }
+                else break;
+            }
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eA[i][j] = eV[i][j];
+            inv6_lu(eA, eVi);
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {      // matP = matV.inv() * matV2
+                double a = 0.0;
+                for (int k = 0; k < 6; k++) a += (double)eVi[i][k] * (double)eV2[k][j];
+                st->matP[i * 6 + j] = (float)a;
+            }
         }
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eA[i][j] = eV[i][j];
-        inv6_lu(eA, eVi);
-        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {          // matP = matV.inv() * matV2
-            double a = 0.0;
-            for (int k = 0; k < 6; k++) a += (double)eVi[i][k] * (double)eV2[k][j];
-            st->matP[i * 6 + j] = (float)a;
-        }
+        // not degenerate: matP is never read before the next scan's iteration 0 rewrites it
         st->isDegenerate = degenerate;
+        __threadfence_block();
     }
-    if (st->isDegenerate) {                             // :1266-1271
-        float X2[6];
+    __syncthreads();
+
+    // ---- lane 0: projection, pose update, convergence test (:1266-1292)
+    s2m_iter_trace tr;
+    bool conv = false;
+    if (t == 0) {
+        float X[6], pose[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) X2[k] = X[k];
-        for (int i = 0; i < 6; i++) {
-            double a = 0.0;
-            for (int k = 0; k < 6; k++) a += (double)st->matP[i * 6 + k] * (double)X2[k];
-            X[i] = (float)a;
+        for (int k = 0; k < 6; k++) { X[k] = sX[k]; pose[k] = st->pose[k]; }
+        if (st->isDegenerate) {                         // :1266-1271
+            float X2[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) X2[k] = X[k];
+            for (int i = 0; i < 6; i++) {
+                double a = 0.0;
+                for (int k = 0; k < 6; k++) a += (double)st->matP[i * 6 + k] * (double)X2[k];
+                X[i] = (float)a;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pose[k] += X[k]; sPose[k] = pose[k]; }   // :1273-1278
+        const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
+        const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);          // :1280-1283
+        const double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
+        const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);          // :1284-1287
+        conv = ((double)deltaR < cp->conv_deg) && ((double)deltaT < cp->conv_cm);   // :1289
+        tr.n_sel = n_sel; tr.stepped = 1; tr.deltaR = deltaR; tr.deltaT = deltaT;
+#pragma unroll
+        for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; }
     }
+    __syncthreads();
+    // ---- lanes 0..2: sin/cos of yaw, pitch, roll for the next launch (:348-351, :1170-1175), in
+    // fp64 rounded once to fp32 (device sinf/cosf are a few ulp off libm's; the double-rounded value
+    // agrees with a correctly rounded fp32 libm result)
+    if (t < 3) {
+        double sn, cs;
+        sincos((double)sPose[2 - t], &sn, &cs);         // t=0: yaw, 1: pitch, 2: roll
+        sSC[2 * t] = (float)sn; sSC[2 * t + 1] = (float)cs;
+    }
+    __syncthreads();
+    if (t == 0) {
+        const float B = sSC[0], A = sSC[1], D = sSC[2], C = sSC[3], F = sSC[4], E = sSC[5];
+        const float DE = D * E, DF = D * F;
+        st->T[0] = A * C; st->T[1] = A * DF - B * E; st->T[2]  = B * F + A * DE; st->T[3]  = sPose[3];
+        st->T[4] = B * C; st->T[5] = A * E + B * DF; st->T[6]  = B * DE - A * F; st->T[7]  = sPose[4];
+        st->T[8] = -D;    st->T[9] = C * F;          st->T[10] = C * E;          st->T[11] = sPose[5];
 #pragma unroll
-    for (int k = 0; k < 6; k++) pose[k] += X[k];        // :1273-1278
-
-    const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
-    const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);               // :1280-1283
-    const double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
-    const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);               // :1284-1287
-    const bool conv = ((double)deltaR < cp->conv_deg) && ((double)deltaT < cp->conv_cm);   // :1289
-
-    tr.stepped = 1; tr.deltaR = deltaR; tr.deltaT = deltaT;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; st->pose[k] = pose[k]; }
-    store_trace(trace + iter, tr);
-
-    float T[12], sc[6];
-    pose_to_transform(pose, T, sc);
-#pragma unroll
-    for (int k = 0; k < 12; k++) st->T[k] = T[k];
-#pragma unroll
-    for (int k = 0; k < 6; k++) st->sc[k] = sc[k];
-    st->iters_run = iter + 1;
-    if (conv && !st->converged) st->converged = 1;
-    if (conv && cp->early_exit) st->done = 1;           // break (:1313-1314)
+        for (int k = 0; k < 6; k++) { st->sc[k] = sSC[k]; st->pose[k] = sPose[k]; }
+        store_trace(trace + iter, tr);
+        st->iters_run = iter + 1;
+        if (conv && !st->converged) st->converged = 1;
+        if (conv && cp->early_exit) st->done = 1;       // break (:1313-1314)
+    }
 }
 
 // Parameter blocks travel as kernel arguments (copied at launch), so the host never has to
