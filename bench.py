@@ -119,6 +119,15 @@ def main():
     kernel_ms = eng.time_iteration_kernel(cfg["pose_init"], reps=10)   # 10 loops x 30 launches, event pair per launch
     b_alg = 12.0 * (n_q + n_m)                             # SoA fp32 xyz read once
     achieved = b_alg / (kernel_ms * 1e-3)
+    # HBM-side bytes per launch from the committed PMC passes (profiles/, same workload): FETCH_SIZE is
+    # doubled (the gfx950 correction for 16-B-per-lane reads, MI355X_MICROARCH.md), WRITE_SIZE as is
+    traffic = traffic_raw = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_k_register_pmc.json")
+    if args.workload == "kitti64" and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        f_kb, w_kb = pmc["FETCH_SIZE"]["mean_KB"], pmc["WRITE_SIZE"]["mean_KB"]
+        traffic_raw = round((f_kb + w_kb) * 1024.0)
+        traffic = round((2.0 * f_kb + w_kb) * 1024.0)
     device_ms = eng.timing()["optimize_ms"]
 
     out = {
@@ -143,7 +152,8 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_register",
             "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw,
+            "traffic_source": "profiles/r01_k_register_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
             "algorithmic_bytes_per_launch": b_alg, "kernel_us": round(kernel_ms * 1e3, 3),
             "frac_of_measured_achievable": round(achieved / HBM_ACHIEVABLE, 5),
         },
