@@ -666,8 +666,9 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
 #define S2M_LAP(acc) do { if (HOOK) { const unsigned long long n__ = wall_clock64(); (acc) += n__ - tk; tk = n__; } } while (0)
 
     constexpr int NW = kBlock / 64;
-    __shared__ v4f    s_pts[NW][kTilePts];
-    __shared__ double red[NW][32];
+    __shared__ v4f     s_pts[NW][kTilePts];
+    __shared__ int32_t s_run[NW][18][64];           // gather path: this lane's 9 (start, end) pairs
+    __shared__ double  red[NW][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // wave w of workgroup b takes entry w*gridDim.x + b of the wave table: neighbouring chunks
@@ -765,7 +766,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
         const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
         bool glanes = false;                              // lanes that take the gather path
-        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 40 * nfin;
+        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * nfin;
         if (HOOK && !tile) dbg_why = 1;
         int nt = 0;                                       // tile fill (wave-uniform)
         for (int rg = 0; rg < R && tile; rg += 64) {
@@ -874,7 +875,8 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         if (!tile) glanes = fin;
         if (__ballot(glanes)) {
             if (HOOK) dbg_mode = tile ? 3 : 2;
-            // ---- gather: run bounds of all 9 rows first (independent loads), then the runs
+            // ---- gather: run bounds of all 9 rows first (independent loads, kept in LDS), then the runs
+            int32_t (*lrun)[64] = s_run[wave];
             if (glanes && !(ablate & 1)) {
                 int rs[9], re[9];
 #pragma unroll
@@ -891,34 +893,79 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                         re[k] = cell_start[rb + xe + 1];
                     }
                 }
-                // software pipeline over the runs: the first 4 points of run k+1 are in flight while
-                // run k is processed (past a run's end its last point is re-read: a dup, rejected for free)
-                v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
-                if (rs[0] < re[0]) { n0 = map[rs[0]]; n1 = map[min(rs[0] + 1, re[0] - 1)]; n2 = map[min(rs[0] + 2, re[0] - 1)]; n3 = map[min(rs[0] + 3, re[0] - 1)]; }
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
-                    if (k < 8) {
-                        if (rs[k + 1] < re[k + 1]) {
-                            const int jn = rs[k + 1], en = re[k + 1];
-                            n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)];
+                for (int k = 0; k < 9; k++) { lrun[2 * k][lane] = rs[k]; lrun[2 * k + 1][lane] = re[k]; }
+            }
+            wave_lds_sync();
+            if (glanes && !(ablate & 1)) {
+                // ---- verify first (same argument as in the tile path): count this lane's candidates
+                // with d2 <= bound, branch-free; a complete prior and a count of 5 settle the lane.
+                // The first 4 points of run k+1 are in flight while run k is counted.
+                bool full_pass = true;
+                {
+                    const bool prior_ok = best.key[4] != kKeyInf && __uint_as_float((uint32_t)(best.key[4] >> 32)) <= bound;
+                    int cnt = 0;
+                    int jn = lrun[0][lane], en = lrun[1][lane];
+                    v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
+                    if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+#pragma unroll 1
+                    for (int k = 0; k < 9; k++) {
+                        const int j0 = jn, e = en;
+                        const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
+                        if (k < 8) {
+                            jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
+                            if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+                        }
+                        if (j0 < e) {
+                            float d0, d1, d2v, d3;
+                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                            cnt += (d0 <= bound) ? 1 : 0;
+                            cnt += (j0 + 1 < e && d1 <= bound) ? 1 : 0;          // past the end the last point was re-read
+                            cnt += (j0 + 2 < e && d2v <= bound) ? 1 : 0;
+                            cnt += (j0 + 3 < e && d3 <= bound) ? 1 : 0;
+                            if (HOOK) dbg_pts += e - j0;
+                            for (int j = j0 + 4; j < e; j += 4) {                  // long runs: 4 loads in flight
+                                const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
+                                make_key(q0, sx, sy, sz, d0); make_key(q1, sx, sy, sz, d1);
+                                make_key(q2, sx, sy, sz, d2v); make_key(q3, sx, sy, sz, d3);
+                                cnt += (d0 <= bound) ? 1 : 0;
+                                cnt += (j + 1 < e && d1 <= bound) ? 1 : 0;
+                                cnt += (j + 2 < e && d2v <= bound) ? 1 : 0;
+                                cnt += (j + 3 < e && d3 <= bound) ? 1 : 0;
+                            }
                         }
                     }
-                    const int dyc = run_dy(k), dzc = run_dz(k);
-                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                    if (rs[k] < re[k] && !(lb > bound)) {                              // bound may have tightened meanwhile
-                        if (HOOK) dbg_pts += re[k] - rs[k];
-                        consider(best, bound, gatef, m0, sx, sy, sz);
-                        consider(best, bound, gatef, m1, sx, sy, sz);
-                        consider(best, bound, gatef, m2, sx, sy, sz);
-                        consider(best, bound, gatef, m3, sx, sy, sz);
-                        for (int j = rs[k] + 4; j < re[k]; j += 4) {                   // long runs: 4 loads in flight
-                            const int e = re[k];
-                            const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
-                            consider(best, bound, gatef, q0, sx, sy, sz);
-                            consider(best, bound, gatef, q1, sx, sy, sz);
-                            consider(best, bound, gatef, q2, sx, sy, sz);
-                            consider(best, bound, gatef, q3, sx, sy, sz);
+                    if (prior_ok && cnt == 5) full_pass = false;
+                    else if (bound >= gatef && cnt < 5) { full_pass = false; certain_far = true; }
+                }
+                // ---- full pass for the lanes that gained, lost or lack a neighbour (lines now L2-warm)
+                if (full_pass) {
+                    int jn = lrun[0][lane], en = lrun[1][lane];
+                    v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
+                    if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+#pragma unroll 1
+                    for (int k = 0; k < 9; k++) {
+                        const int j0 = jn, e = en;
+                        const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
+                        if (k < 8) {
+                            jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
+                            if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+                        }
+                        const int dyc = run_dy(k), dzc = run_dz(k);
+                        const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
+                        if (j0 < e && !(lb > bound)) {                                 // bound may have tightened meanwhile
+                            consider(best, bound, gatef, m0, sx, sy, sz);
+                            consider(best, bound, gatef, m1, sx, sy, sz);
+                            consider(best, bound, gatef, m2, sx, sy, sz);
+                            consider(best, bound, gatef, m3, sx, sy, sz);
+                            for (int j = j0 + 4; j < e; j += 4) {                      // long runs: 4 loads in flight
+                                const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
+                                consider(best, bound, gatef, q0, sx, sy, sz);
+                                consider(best, bound, gatef, q1, sx, sy, sz);
+                                consider(best, bound, gatef, q2, sx, sy, sz);
+                                consider(best, bound, gatef, q3, sx, sy, sz);
+                            }
                         }
                     }
                 }
@@ -1049,7 +1096,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         const auto d = G(cp->dbg_clk) + 16 * ((size_t)blockIdx.x * NW + wave);
         d[0] = tk_start; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
         d[4] = (unsigned long long)dbg_mode; d[5] = (unsigned long long)dbg_rows; d[6] = (unsigned long long)dbg_pts; d[7] = (unsigned long long)dbg_raw;
-        d[8] = t_bbox; d[9] = t_mark; d[10] = 0; d[11] = t_stage; d[12] = t_search; d[13] = (unsigned long long)dbg_why; d[14] = (unsigned long long)dbg_box; d[15] = (unsigned long long)dbg_skip;
+        d[8] = t_bbox; d[9] = t_mark; d[10] = (unsigned long long)chunk.y; d[11] = t_stage; d[12] = t_search; d[13] = (unsigned long long)dbg_why; d[14] = (unsigned long long)dbg_box; d[15] = (unsigned long long)dbg_skip;
     }
     __syncthreads();
     if (tid < kAcc) {

@@ -25,7 +25,10 @@ if os.environ.get("S2M_WAVES"):
     print("slowest waves: total_us path(1=tile,2=gather,3=tile then gather) rows pts raw why(1 rows,2 raw,3 overflow) box(x,y,z) lanes_in_full_sweep(tile)|max_lane_candidates(gather)")
     for i in o:
         b = int(w[i, 14])
-        print("   %.2f %d %d %d %d %d (%d,%d,%d) %d" % (tot[i], w[i, 4], w[i, 5], w[i, 6], w[i, 7], w[i, 13], b >> 20, (b >> 10) & 1023, b & 1023, w[i, 15]))
+        print("   %.2f %d %d %d %d %d (%d,%d,%d) %d  n=%d  [box %.1f mark %.1f stage %.1f search %.1f]" % (tot[i], w[i, 4], w[i, 5], w[i, 6], w[i, 7], w[i, 13], b >> 20, (b >> 10) & 1023, b & 1023, w[i, 15], w[i, 10], w[i, 8] / 100.0, w[i, 9] / 100.0, w[i, 11] / 100.0, w[i, 12] / 100.0))
+    for cnt in (64, 32, 16):
+        sel = w[:, 10] == cnt
+        if sel.any(): print("waves with %d points: %d, total med %.2f p99 %.2f max %.2f us" % (cnt, sel.sum(), np.median(tot[sel]), np.percentile(tot[sel], 99), tot[sel].max()))
     tl = w[:, 4] == 1
     print("tile waves needing the full sweep: %d of %d; lanes in full sweep: %d" % ((w[tl, 15] > 0).sum(), tl.sum(), w[tl, 15].sum()))
     for why in (1, 2, 3):
