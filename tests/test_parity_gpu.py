@@ -216,3 +216,90 @@ def test_cpp_host_mirror_matches_oracle(tmp_path, cfg_tiny):
     ro = orc.scan2MapOptimization(np.array([float("%.9g" % v) for v in pose], np.float32))
     assert ("iters %d " % ro.iters_run) in lines[0]
     assert np.abs(got - np.array(ro.pose)).max() <= 1e-4
+
+
+# ----------------------------------------------------------------------------- hard cases
+def _compare_surf(gpu, m, s, pose, **kw):
+    gpu.setInputCloud(m)
+    gpu.setScan(s)
+    orc = O.Oracle(knn_backend=0, num_threads=8, **kw)
+    orc.set_map(m)
+    orc.set_scan(s)
+    out = []
+    for p in (pose, pose + np.float32(1e-3), pose):          # 2nd/3rd call run with a prior from the call before
+        idx, d2, flag, coeff = gpu.surfOptimization(p)
+        oidx, od2, oflag, ocoeff = orc.surfOptimization(p)
+        gated = oidx[:, 0] >= 0
+        assert np.array_equal(idx[:, 0] >= 0, gated)
+        assert np.array_equal(idx[gated], oidx[gated])
+        assert np.array_equal(d2[gated].view(np.uint32), od2[gated].view(np.uint32))
+        assert np.array_equal(flag, oflag) and np.array_equal(coeff.view(np.uint32), ocoeff.view(np.uint32))
+        out.append(gated.mean())
+    return out
+
+
+def test_exact_distance_ties_break_by_index(gpu):
+    """A lattice map and lattice-centred queries give many exactly equal distances: the 5 neighbours and
+    their order must still be the oracle's (smaller map index first), with and without a prior."""
+    g = np.arange(-6, 7, dtype=np.float32) * np.float32(0.5)
+    X, Y, Z = np.meshgrid(g, g, np.array([-1.0, -0.5, 0.0], np.float32), indexing="ij")
+    m = np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(np.float32)
+    rng = np.random.default_rng(5)
+    m = m[rng.permutation(len(m))]                         # index order unrelated to position
+    q = np.stack([rng.integers(-8, 9, 600) * 0.25, rng.integers(-8, 9, 600) * 0.25,
+                  rng.integers(-4, 1, 600) * 0.25], 1).astype(np.float32)
+    pose = np.zeros(6, np.float32)                         # identity: queries stay on the half-lattice
+    gated = _compare_surf(gpu, m, q, pose)
+    assert gated[0] > 0.9
+
+
+def test_non_finite_points_are_harmless(gpu, cfg_tiny):
+    m, s = cfg_tiny["map"].copy(), cfg_tiny["scan"].copy()
+    m[5] = [np.nan, 0, 0]
+    m[17] = [np.inf, 1, 1]
+    s[3] = [np.nan, np.nan, np.nan]
+    s[40] = [np.inf, 0, 0]
+    s[41] = [1e30, -1e30, 0]
+    gated = _compare_surf(gpu, m, s, cfg_tiny["pose_init"])
+    assert gated[0] > 0.5
+
+
+def test_scattered_scan_takes_the_gather_path(gpu, cfg_small):
+    """Random order + sparse far-apart queries: big boxes, several row groups, gather and overflow paths."""
+    rng = np.random.default_rng(11)
+    m = cfg_small["map"]
+    # queries: a few map points jittered, spread over the whole scene (every wave's box is huge)
+    q = (m[rng.choice(len(m), 1500, replace=False)] + rng.normal(0, 0.15, (1500, 3))).astype(np.float32)
+    pose = np.array([0, 0, 0, 0.05, -0.03, 0.02], np.float32)
+    gated = _compare_surf(gpu, m, q, pose)
+    assert gated[0] > 0.5
+    # and a dense clump inside a dense region (tile overflow -> per-lane gather)
+    c = m[np.argmax(np.bincount((m[:, 0] // 2).astype(int) - int(m[:, 0].min() // 2)))]
+    q2 = (c + rng.normal(0, 1.5, (3000, 3))).astype(np.float32)
+    _compare_surf(gpu, m, q2, pose)
+
+
+def test_tiny_and_ragged_sizes(gpu, cfg_tiny):
+    m, s = cfg_tiny["map"], cfg_tiny["scan"]
+    for n_q in (1, 5, 63, 64, 65, 129):
+        _compare_surf(gpu, m, s[:n_q], cfg_tiny["pose_init"])
+    for n_m in (1, 4, 5, 6, 40):                            # fewer than 5 map points: nothing is gated
+        _compare_surf(gpu, m[:n_m], s[:200], cfg_tiny["pose_init"])
+
+
+def test_loop_parity_after_map_and_scan_changes(gpu, cfg_tiny, cfg_small):
+    """Handles are reused across scans and maps: priors and plane caches must not leak between them."""
+    for cfg in (cfg_small, cfg_tiny, cfg_small):
+        orc = _pair(gpu, cfg, knn_backend=1)
+        gpu.transformTobeMapped = cfg["pose_init"].copy()
+        r = gpu.scan2MapOptimization()
+        ro = orc.scan2MapOptimization(cfg["pose_init"])
+        assert r.iters_run == ro.iters_run
+        assert np.abs(np.array(r.pose) - np.array(ro.pose)).max() <= 1e-4
+        # same scan again, different start: the prior now comes from the previous call's last iteration
+        p2 = (cfg["pose_init"] + np.float32(0.01)).astype(np.float32)
+        gpu.transformTobeMapped = p2.copy()
+        r = gpu.scan2MapOptimization()
+        ro = orc.scan2MapOptimization(p2)
+        assert r.iters_run == ro.iters_run
+        assert np.abs(np.array(r.pose) - np.array(ro.pose)).max() <= 1e-4
