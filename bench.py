@@ -85,6 +85,8 @@ def main():
     max_iter = eng.params.max_iter
 
 
+    gatherer = batch.RecordGatherer(world, device=dev) if world > 1 else None
+
     def step():
         # one scan2MapOptimization(): scan ordering/SoA prep + 30 x {k_register, k_finalize}; the map
         # index (the reference's kd-tree build, once per scan) is timed separately, see map_index_build_ms
@@ -92,7 +94,7 @@ def main():
         eng.launch(cfg["pose_init"])
         r = eng.collect()
         if world > 1:      # RCCL all-gather of {pose[6], iters, n_sel} over xGMI: every rank gets all poses
-            batch.gather_records(batch.pack_record(r.pose, r.iters_run, r.n_sel_last)[None, :], world, device=dev)
+            gatherer.gather(batch.pack_record(r.pose, r.iters_run, r.n_sel_last)[None, :])
         return r
 
     def fence():

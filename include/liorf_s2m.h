@@ -168,11 +168,12 @@ int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float*
  * returns the mean duration of those launches in ms. */
 int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float* ms_per_launch);
 
-/* Diagnostics: one k_register pass at `pose`; per wave (64 locality-sorted scan points) 16 words:
+/* Diagnostics: `launches` k_register passes at `pose` (the last one is recorded; 1 = the pass that
+ * inherits its prior from whatever ran before, 3 = steady state at this pose); per wave (64 locality-sorted scan points) 16 words:
  * wall-clock (100 MHz) at start / after the search / after plane+Jacobian / at end; search path
  * (1 LDS tile, 2 gather), box rows, points visited, 0; ticks spent in prior+box / row marking /
  * (unused) / staging / search; 3 spare. Returns the number of waves written (<= cap_waves). */
-int  s2m_debug_wave_profile(s2m_handle h, const float pose[6], uint64_t* out, size_t cap_waves);
+int  s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint64_t* out, size_t cap_waves);
 
 /* ---- ScanContext descriptor (BASELINE config 5) ------------------------- */
 /* SCManager::makeScancontext + makeRingkeyFromScancontext

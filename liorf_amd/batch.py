@@ -28,30 +28,53 @@ def pack_record(pose, iters_run: int, n_sel: int) -> np.ndarray:
     return rec
 
 
+class RecordGatherer:
+    """Pre-allocated buffers for the per-batch all-gather (one collective, one D2H copy per batch)."""
+
+    def __init__(self, n_scans: int, device: torch.device | str = "cpu", group=None):
+        self.n_scans = n_scans
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.per_rank = max(1, (n_scans + self.world - 1) // self.world)
+        self.mine = shard_scans(n_scans, self.world, self.rank)
+        pin = torch.device(device).type == "cuda"
+        self.h_send = torch.full((self.per_rank, RECORD_FLOATS), float("nan"), dtype=torch.float32, pin_memory=pin)
+        self.d_send = torch.empty((self.per_rank, RECORD_FLOATS), dtype=torch.float32, device=device)
+        self.d_recv = torch.empty((self.world * self.per_rank, RECORD_FLOATS), dtype=torch.float32, device=device)
+        self.h_recv = torch.empty((self.world * self.per_rank, RECORD_FLOATS), dtype=torch.float32, pin_memory=pin)
+        # scan index of every row of the gathered table (rank-major), -1 for padding rows
+        self.row_scan = np.full(self.world * self.per_rank, -1, np.int64)
+        for r in range(self.world):
+            for k, scan in enumerate(shard_scans(n_scans, self.world, r)):
+                self.row_scan[r * self.per_rank + k] = scan
+
+    def gather(self, local: np.ndarray) -> np.ndarray:
+        mine = np.asarray(local, np.float32).reshape(-1, RECORD_FLOATS)
+        if mine.shape[0] != len(self.mine):
+            raise ValueError("record count does not match this rank's shard")
+        self.h_send.fill_(float("nan"))
+        if mine.shape[0]:
+            self.h_send[: mine.shape[0]] = torch.from_numpy(mine)
+        if self.world == 1:
+            rows = self.h_send.numpy()
+        else:
+            self.d_send.copy_(self.h_send, non_blocking=True)
+            dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group)
+            self.h_recv.copy_(self.d_recv)                 # the one synchronising copy of the batch
+            rows = self.h_recv.numpy()
+        table = np.full((self.n_scans, RECORD_FLOATS), np.nan, np.float32)
+        ok = self.row_scan[: rows.shape[0]] >= 0
+        table[self.row_scan[: rows.shape[0]][ok]] = rows[ok]
+        return table
+
+
 def gather_records(local: np.ndarray, n_scans: int, device: torch.device | str = "cpu", group=None) -> np.ndarray:
     """All-gather the per-rank records of one batch.
 
     `local` holds this rank's records in the order of shard_scans(); every rank returns the
     (n_scans, 8) table indexed by scan.  Ranks with fewer scans pad with NaN rows (one fixed-size
     all_gather instead of a variable-size exchange: the payload is a few hundred bytes, latency-bound).
+    Callers in a loop should keep a RecordGatherer instead (buffers allocated once).
     """
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    per_rank = (n_scans + world - 1) // world
-    buf = torch.full((per_rank, RECORD_FLOATS), float("nan"), dtype=torch.float32)
-    mine = np.asarray(local, np.float32).reshape(-1, RECORD_FLOATS)
-    if mine.shape[0] != len(shard_scans(n_scans, world, rank)):
-        raise ValueError("record count does not match this rank's shard")
-    buf[: mine.shape[0]] = torch.from_numpy(mine)
-    buf = buf.to(device)
-    if world == 1:
-        table = buf.cpu().numpy()[:n_scans]
-        return table
-    out = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(out, buf, group=group)
-    table = np.full((n_scans, RECORD_FLOATS), np.nan, np.float32)
-    for r in range(world):
-        rows = out[r].cpu().numpy()
-        for k, scan in enumerate(shard_scans(n_scans, world, r)):
-            table[scan] = rows[k]
-    return table
+    return RecordGatherer(n_scans, device, group).gather(local)

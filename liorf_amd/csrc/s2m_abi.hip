@@ -45,7 +45,7 @@ struct s2m_context {
     // map side
     DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
     // scan side
-    DevBuf raw_scan, qx, qy, qz, qperm, prevp, plane_cache, plane_state, chunk_parts, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
+    DevBuf raw_scan, qx, qy, qz, qperm, prevp, prior_valid, plane_cache, plane_state, chunk_parts, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
 
@@ -215,8 +215,8 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
                        (const int32_t*)h->m_cell_start.as<int32_t>(), h->map_sorted.as<float4>());
     S2M_HIP(h, hipGetLastError());
 
-    if (h->have_scan && h->n_q > 0 && h->prevp.p)      // neighbours of the old map are meaningless now
-        S2M_HIP(h, hipMemsetAsync(h->prevp.p, 0xff, sizeof(float4) * 5 * h->n_q, h->stream));
+    if (h->have_scan && h->n_q > 0 && h->prior_valid.p)      // neighbours of the old map are meaningless now
+        S2M_HIP(h, hipMemsetAsync(h->prior_valid.p, 0, sizeof(int32_t) * h->n_q, h->stream));
     h->hctx.g = g;
     h->hctx.map_sorted = h->map_sorted.as<float4>();
     h->hctx.cell_start = h->m_cell_start.as<int32_t>();
@@ -238,7 +238,8 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     h->hctx.n_q = (int32_t)n;
     // wave table capacity: every 64-point chunk plus a 50 % budget of extra waves for split chunks
     const int n_chunks = (int)((n + 63) / 64);
-    int nblocks = (n_chunks + n_chunks / 2 + 3) / 4;
+    constexpr int NW = kBlock / 64;
+    int nblocks = (n_chunks + n_chunks / 2 + NW - 1) / NW;
     nblocks = ((nblocks + kBlocksQuantum - 1) / kBlocksQuantum) * kBlocksQuantum;
     if (nblocks == 0) nblocks = kBlocksQuantum;
     h->hctx.nblocks = nblocks;
@@ -263,7 +264,8 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     if ((rc = ensure(h, h->plane_cache, sizeof(float4) * n))) return rc;
     if ((rc = ensure(h, h->plane_state, sizeof(int32_t) * n))) return rc;
     S2M_HIP(h, hipMemsetAsync(h->plane_state.p, 0, sizeof(int32_t) * n, h->stream));
-    S2M_HIP(h, hipMemsetAsync(h->prevp.p, 0xff, sizeof(float4) * 5 * n, h->stream));   // no prior for a new scan (index -1)
+    if ((rc = ensure(h, h->prior_valid, sizeof(int32_t) * n))) return rc;
+    S2M_HIP(h, hipMemsetAsync(h->prior_valid.p, 0, sizeof(int32_t) * n, h->stream));     // no prior for a new scan
     if ((rc = ensure(h, h->q_counts, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
@@ -297,6 +299,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
         h->hctx.n_waves = h->n_waves.as<int32_t>();
     }
     h->hctx.prevp = h->prevp.as<float4>();
+    h->hctx.prior_valid = h->prior_valid.as<int32_t>();
     h->hctx.plane_cache = h->plane_cache.as<float4>();
     h->hctx.plane_state = h->plane_state.as<int32_t>();
     h->ctx_dirty = true;
@@ -310,6 +313,7 @@ void fill_state(s2m_context* h, DevState* s, const float pose[6])
     memset(s, 0, sizeof(*s));
     memcpy(s->pose, pose, 24);
     host_pose_to_transform(pose, s->T, s->sc);
+    s->T_valid = 1;
     memcpy(s->matP, h->persist_matP, sizeof(s->matP));
     s->isDegenerate = h->persist_degenerate;
 }
@@ -460,7 +464,7 @@ int s2m_destroy(s2m_handle h)
     for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : h->iter_events) hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
-                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->plane_cache, &h->plane_state, &h->chunk_parts, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->prior_valid, &h->plane_cache, &h->plane_state, &h->chunk_parts, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out };
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
@@ -606,9 +610,9 @@ int s2m_surf_optimization(s2m_handle h, const float pose[6], int32_t* idx5, floa
     return upload_ctx(h);
 }
 
-int s2m_debug_wave_profile(s2m_handle h, const float pose[6], uint64_t* out, size_t cap_waves)
+int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint64_t* out, size_t cap_waves)
 {
-    if (!h || !pose || !out) return S2M_ERR_INVALID_ARG;
+    if (!h || !pose || !out || launches < 1) return S2M_ERR_INVALID_ARG;
     if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
     S2M_HIP(h, hipSetDevice(h->device));
     const size_t nwaves = (size_t)h->hctx.nblocks * (kBlock / 64);   // kWaveQ points each
@@ -619,7 +623,7 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], uint64_t* out, siz
     h->ctx_dirty = true;
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
-    for (int rep = 0; rep < 3; rep++)       // last pass is the warm one
+    for (int rep = 0; rep < launches; rep++)
         hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>());
     S2M_HIP(h, hipGetLastError());
     const size_t n = nwaves < cap_waves ? nwaves : cap_waves;
@@ -690,7 +694,7 @@ int s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float
     long launches = 0;
     for (int rep = 0; rep < reps; rep++) {
         // a new scan starts without a prior or cached planes (what s2m_set_scan leaves behind)
-        S2M_HIP(h, hipMemsetAsync(h->prevp.p, 0xff, sizeof(float4) * 5 * h->n_q, h->stream));
+        S2M_HIP(h, hipMemsetAsync(h->prior_valid.p, 0, sizeof(int32_t) * h->n_q, h->stream));
         S2M_HIP(h, hipMemsetAsync(h->plane_state.p, 0, sizeof(int32_t) * h->n_q, h->stream));
         if ((rc = push_state(h, pose))) return rc;
         for (int it = 0; it < nit; it++) {          // the real loop, launched one by one between event pairs

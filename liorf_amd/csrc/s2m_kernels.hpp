@@ -89,23 +89,23 @@ __device__ __forceinline__ int lin_rows(const GridDesc& g, int cx, int cy, int c
     return (cz * g.ny + cy) * g.nx + cx;
 }
 // Scan locality order (ordering only, never results): lidar returns are binned on a
-// log-polar grid around the sensor (256 azimuth x 128 log-range bins; cell size grows with
+// log-polar grid around the sensor (128 azimuth x 128 log-range bins; cell size grows with
 // range like the return spacing does, so cells hold a few points each and the rank atomics
 // do not pile up on the dense near-field cells), numbered along a Hilbert curve so that 64
 // consecutive sorted points form a compact patch; a rigid transform keeps it compact.
-constexpr int kPolarCells = 65536;
-// Hilbert curve index of (x, y) on a 256 x 256 grid: consecutive indices are always adjacent
+constexpr int kPolarCells = 16384;
+// Hilbert curve index of (x, y) on a 128 x 128 grid: consecutive indices are always adjacent
 // cells (a Z-order curve jumps across the grid at every power-of-two boundary, and a wave that
 // straddles a jump gets a huge bounding box).
-__device__ __forceinline__ uint32_t hilbert256(uint32_t x, uint32_t y)
+__device__ __forceinline__ uint32_t hilbert128(uint32_t x, uint32_t y)
 {
     uint32_t d = 0;
 #pragma unroll
-    for (uint32_t s = 128; s > 0; s >>= 1) {
+    for (uint32_t s = 64; s > 0; s >>= 1) {
         const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
         d += s * s * ((3u * rx) ^ ry);
         if (ry == 0) {
-            if (rx == 1) { x = 255u - x; y = 255u - y; }
+            if (rx == 1) { x = 127u - x; y = 127u - y; }
             const uint32_t t = x; x = y; y = t;
         }
     }
@@ -115,12 +115,12 @@ __device__ __forceinline__ int polar_cell(float x, float y)
 {
     const float rho = sqrtf(x * x + y * y);
     float az = atan2f(y, x);                                  // [-pi, pi]
-    int ab = (int)((az + 3.14159265f) * (256.0f / 6.2831853f));
-    ab = min(max(ab, 0), 255);
+    int ab = (int)((az + 3.14159265f) * (128.0f / 6.2831853f));
+    ab = min(max(ab, 0), 127);
     float lr = (__log2f(fmaxf(rho, 0.5f)) + 1.0f) * (128.0f / 9.23f);   // 0.5 m .. 300 m
     int rb = (rho == rho) ? min(max((int)lr, 0), 127) : 0;
     if (!(az == az)) ab = 0;
-    return (int)hilbert256((uint32_t)ab, (uint32_t)rb);
+    return (int)hilbert128((uint32_t)ab, (uint32_t)rb);
 }
 
 __global__ void k_polar_count(const unsigned char* __restrict__ pts, size_t stride, int n,
@@ -135,16 +135,16 @@ __global__ void k_polar_count(const unsigned char* __restrict__ pts, size_t stri
     rank_of[i] = atomicAdd(&counts[c], 1);
 }
 
-// exclusive scan of the 65536 polar cell counts by one workgroup (64 per thread)
+// exclusive scan of the 16384 polar cell counts by one workgroup (16 per thread)
 __global__ __launch_bounds__(1024) void k_polar_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ start)
 {
     __shared__ int32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    int32_t v[64];
+    int32_t v[16];
     int32_t sum = 0;
-    const int4* c4 = reinterpret_cast<const int4*>(counts + t * 64);
+    const int4* c4 = reinterpret_cast<const int4*>(counts + t * 16);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < 4; k++) {
         const int4 q = c4[k];
         v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
         sum += q.x + q.y + q.z + q.w;
@@ -160,9 +160,9 @@ __global__ __launch_bounds__(1024) void k_polar_scan(const int32_t* __restrict__
     int32_t woff = 0;
     for (int w = 0; w < wave; w++) woff += wsum[w];
     int32_t run = woff + incl - sum;
-    int4* s4 = reinterpret_cast<int4*>(start + t * 64);
+    int4* s4 = reinterpret_cast<int4*>(start + t * 16);
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < 4; k++) {
         int4 q;
         q.x = run; run += v[4 * k];
         q.y = run; run += v[4 * k + 1];
@@ -543,9 +543,8 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // No barrier is needed until the final reduction: a wave only reads LDS it wrote itself.
 // combineOptimizationCoeffs() (:1145-1156) has no counterpart: rejected lanes contribute zeros.
 // ------------------------------------------------------------------------------------------
-constexpr int kTilePts = 448;        // points per wave tile (7 KiB) after filtering
-constexpr int kTilePtsCold = 128;    // largest tile a lane sweeps with the full insertion test; beyond it that lane gathers
-constexpr int kTileRaw = 704;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
+constexpr int kTilePts = 320;        // points per wave tile (5 KiB) after filtering
+constexpr int kTileRaw = 448;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
 constexpr int kRowMax = 256;         // boxes with more rows go straight to the gather path
 constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning (<= 5e-5)
 constexpr uint64_t kKeyInf = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu;
@@ -659,13 +658,13 @@ __device__ __forceinline__ constexpr int run_dz(int k) { return (int)((164373u >
 template <bool HOOK>
 __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ cp)
 {
+    constexpr int NW = kBlock / 64;
     const auto st = G((const DevState*)cp->state);
     if (!HOOK && st->done) return;
     unsigned long long tk_start = 0, tk = 0, t_bbox = 0, t_mark = 0, t_stage = 0, t_search = 0;
     if (HOOK) { tk_start = wall_clock64(); tk = tk_start; }
 #define S2M_LAP(acc) do { if (HOOK) { const unsigned long long n__ = wall_clock64(); (acc) += n__ - tk; tk = n__; } } while (0)
 
-    constexpr int NW = kBlock / 64;
     __shared__ v4f     s_pts[NW][kTilePts];
     __shared__ int32_t s_run[NW][18][64];           // gather path: this lane's 9 (start, end) pairs
     __shared__ double  red[NW][32];
@@ -674,9 +673,12 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     // wave w of workgroup b takes entry w*gridDim.x + b of the wave table: neighbouring chunks
     // (similar cost: the sort runs from the dense near field to the sparse far field) land on
     // different CUs, which evens out both the work and the L2-miss queues
-    const int wg = wave * (int)gridDim.x + (int)blockIdx.x;
+    const int n_waves = *G(cp->n_waves);
+    const int nb_act = (n_waves + NW - 1) / NW;            // workgroups the wave table needs
+    if ((int)blockIdx.x >= nb_act) return;                 // the rest of the (fixed, graph-captured) grid idles
+    const int wg = wave * nb_act + (int)blockIdx.x;
     int2 chunk = make_int2(0, 0);
-    if (wg < *G(cp->n_waves)) { const auto tb = G((const int2*)cp->wave_table); chunk.x = tb[wg].x; chunk.y = tb[wg].y; }
+    if (wg < n_waves) { const auto tb = G((const int2*)cp->wave_table); chunk.x = tb[wg].x; chunk.y = tb[wg].y; }
     const int i = chunk.x + lane;
     const int nq = cp->n_q;
     const bool valid = lane < chunk.y && i < nq;
@@ -689,25 +691,54 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     const int ablate = cp->ablate;
     const float gatef = cp->gate_f;
 
+    // transPointAssociateToMap (:1069-1072) and the LM trig (:1170-1175). Launch 0 of a scan gets them
+    // from the host (libm); later launches rebuild them from the pose k_finalize left behind: lanes
+    // 0..2 take one angle each (fp64 sincos rounded once to fp32), hidden behind the first loads.
+    float T[12], sc6[6];
+    if (st->T_valid) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = st->T[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sc6[k] = st->sc[k];
+    } else {
+        const float ang = st->pose[2 - min(lane, 2)];            // lane 0: yaw, 1: pitch, 2: roll
+        double sn, cs;
+        sincos((double)ang, &sn, &cs);
+        const float snf = (float)sn, csf = (float)cs;
+        const float B = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 0)), A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 0));
+        const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 1)), C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 1));
+        const float F = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 2)), E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 2));
+        const float DE = D * E, DF = D * F;
+        T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = st->pose[3];
+        T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = st->pose[4];
+        T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = st->pose[5];
+        sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
+    }
+
     float px = 0.0f, py = 0.0f, pz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
     Top5 best;
 #pragma unroll
     for (int k = 0; k < 5; k++) { best.key[k] = kKeyInf; best.x[k] = 0.0f; best.y[k] = 0.0f; best.z[k] = 0.0f; }
     float bound = gatef;
     int pidx[5] = { -1, -1, -1, -1, -1 };
+    v4f pl_early = { 0, 0, 0, 0 };
+    int pst_early = 0;
 
     if (valid) {
         v4f pm[5];
 #pragma unroll
         for (int j = 0; j < 5; j++) pm[j] = prevp[(size_t)j * nq + i];
+        const int pvalid = G(cp->prior_valid)[i];
         px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
+        pl_early = G((const v4f*)cp->plane_cache)[i];      // in flight during the search (used if the tuple is unchanged)
+        pst_early = G(cp->plane_state)[i];
         // pointAssociateToMap (:302-308), association order of the reference expression
-        sx = ((st->T[0] * px + st->T[1] * py) + st->T[2]  * pz) + st->T[3];
-        sy = ((st->T[4] * px + st->T[5] * py) + st->T[6]  * pz) + st->T[7];
-        sz = ((st->T[8] * px + st->T[9] * py) + st->T[10] * pz) + st->T[11];
+        sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
+        sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
+        sz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
 #pragma unroll
-        for (int j = 0; j < 5; j++) pidx[j] = __float_as_int(pm[j].w);
-        if (pidx[0] >= 0 && !(ablate & 16)) {            // prior: 5 distinct map points
+        for (int j = 0; j < 5; j++) pidx[j] = pvalid ? __float_as_int(pm[j].w) : -1;
+        if (pvalid && !(ablate & 16)) {                  // prior: 5 distinct map points
 #pragma unroll
             for (int j = 0; j < 5; j++) {
                 float d2;
@@ -768,7 +799,10 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         bool glanes = false;                              // lanes that take the gather path
         bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * nfin;
         if (HOOK && !tile) dbg_why = 1;
-        int nt = 0;                                       // tile fill (wave-uniform)
+        int nt = 0, ntf = 0;                              // tile fill from the front (near) and the back (far), wave-uniform
+        const float wcx = 0.5f * (mnx + mxx), wcy = 0.5f * (mny + mxy), wcz = 0.5f * (mnz + mxz);
+        const float whd = 0.5f * sqrtf(((mxx - mnx) * (mxx - mnx) + (mxy - mny) * (mxy - mny)) + (mxz - mnz) * (mxz - mnz));
+        const float near2 = (whd + 0.45f) * (whd + 0.45f);
         for (int rg = 0; rg < R && tile; rg += 64) {
             // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
             unsigned long long need = 0ull;
@@ -814,13 +848,19 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                     if (hc) pc_v = map[gsc + k];
                     const bool ia = ha && pa_v.x >= fx0 && pa_v.x <= fx1 && pa_v.y >= fy0 && pa_v.y <= fy1 && pa_v.z >= fz0 && pa_v.z <= fz1;
                     const bool ic = hc && pc_v.x >= fx0 && pc_v.x <= fx1 && pc_v.y >= fy0 && pc_v.y <= fy1 && pc_v.z >= fz0 && pc_v.z <= fz1;
-                    const unsigned long long ma = __ballot(ia), mc = __ballot(ic);
-                    const int ca_n = __popcll(ma), cc_n = __popcll(mc);
-                    if (nt + ca_n + cc_n > tile_cap) { tile = false; if (HOOK) dbg_why = 3; break; }
+                    // near the wave's centre -> front of the tile, the rest -> back: a full sweep then
+                    // meets every lane's likely neighbours first and its bound is tight for the remainder
+                    const float ax = pa_v.x - wcx, ay = pa_v.y - wcy, az = pa_v.z - wcz;
+                    const float bx = pc_v.x - wcx, by = pc_v.y - wcy, bz = pc_v.z - wcz;
+                    const bool na_ = (ax * ax + ay * ay) + az * az <= near2, nc_ = (bx * bx + by * by) + bz * bz <= near2;
+                    const unsigned long long man = __ballot(ia && na_), maf = __ballot(ia && !na_);
+                    const unsigned long long mcn = __ballot(ic && nc_), mcf = __ballot(ic && !nc_);
+                    const int an = __popcll(man), af = __popcll(maf), cn = __popcll(mcn), cf = __popcll(mcf);
+                    if (nt + ntf + an + af + cn + cf > tile_cap) { tile = false; if (HOOK) dbg_why = 3; break; }
                     const unsigned long long below = (1ull << lane) - 1ull;
-                    if (ia) lpts[nt + __popcll(ma & below)] = pa_v;
-                    if (ic) lpts[nt + ca_n + __popcll(mc & below)] = pc_v;
-                    nt += ca_n + cc_n;
+                    if (ia) lpts[na_ ? nt + __popcll(man & below) : tile_cap - 1 - (ntf + __popcll(maf & below))] = pa_v;
+                    if (ic) lpts[nc_ ? nt + an + __popcll(mcn & below) : tile_cap - 1 - (ntf + af + __popcll(mcf & below))] = pc_v;
+                    nt += an + cn; ntf += af + cf;
                 }
             }
             S2M_LAP(t_stage);
@@ -828,7 +868,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
 
         if (tile) {
             wave_lds_sync();
-            if (HOOK) { dbg_mode = 1; dbg_pts = nt; }
+            if (HOOK) { dbg_mode = 1; dbg_pts = nt + ntf; }
             // ---- verify: count the tile points with d2 <= bound (branch-free, ~10 VALU a point).
             //  - complete prior and exactly 5: no OTHER point lies within the prior's 5th distance (all 5
             //    prior points are in the tile: their rows were marked and they pass the filter), so the
@@ -839,34 +879,38 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
                 const bool prior_ok = fin && best.key[4] != kKeyInf &&
                                       __uint_as_float((uint32_t)(best.key[4] >> 32)) <= bound;
                 int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                int j = 0;
-                for (; j + 4 <= nt; j += 4) {
-                    const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                    float d0, d1, d2v, d3;
-                    make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                    make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                    c0 += (d0 <= bound) ? 1 : 0; c1 += (d1 <= bound) ? 1 : 0;
-                    c2 += (d2v <= bound) ? 1 : 0; c3 += (d3 <= bound) ? 1 : 0;
+                for (int seg = 0; seg < 2; seg++) {
+                    const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                    int j = jb;
+                    for (; j + 4 <= je; j += 4) {
+                        const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                        float d0, d1, d2v, d3;
+                        make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                        make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                        c0 += (d0 <= bound) ? 1 : 0; c1 += (d1 <= bound) ? 1 : 0;
+                        c2 += (d2v <= bound) ? 1 : 0; c3 += (d3 <= bound) ? 1 : 0;
+                    }
+                    for (; j < je; j++) { float d; make_key(lpts[j], sx, sy, sz, d); c0 += (d <= bound) ? 1 : 0; }
                 }
-                for (; j < nt; j++) { float d; make_key(lpts[j], sx, sy, sz, d); c0 += (d <= bound) ? 1 : 0; }
                 const int cnt = c0 + c1 + c2 + c3;
                 if (prior_ok && cnt == 5) todo = false;
                 else if (fin && bound >= gatef && cnt < 5) { todo = false; certain_far = true; }
             }
-            // ---- sweep: lanes with a new, lost or missing neighbour examine every tile point (a big
-            // tile costs more per lane than that lane's own 27 cells: those lanes gather instead)
-            if (!(ablate & 1) && __ballot(todo) && nt > kTilePtsCold) { glanes = todo; todo = false; }
+            // ---- sweep: lanes with a new, lost or missing neighbour examine the tile, near segment first
             if (!(ablate & 1) && __ballot(todo)) {
                 if (todo) {
-                    int j = 0;
-                    for (; j + 4 <= nt; j += 4) {
-                        const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                        consider(best, bound, gatef, m0, sx, sy, sz);
-                        consider(best, bound, gatef, m1, sx, sy, sz);
-                        consider(best, bound, gatef, m2, sx, sy, sz);
-                        consider(best, bound, gatef, m3, sx, sy, sz);
+                    for (int seg = 0; seg < 2; seg++) {
+                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                        int j = jb;
+                        for (; j + 4 <= je; j += 4) {
+                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                            consider(best, bound, gatef, m0, sx, sy, sz);
+                            consider(best, bound, gatef, m1, sx, sy, sz);
+                            consider(best, bound, gatef, m2, sx, sy, sz);
+                            consider(best, bound, gatef, m3, sx, sy, sz);
+                        }
+                        for (; j < je; j++) consider(best, bound, gatef, lpts[j], sx, sy, sz);
                     }
-                    for (; j < nt; j++) consider(best, bound, gatef, lpts[j], sx, sy, sz);
                 }
                 if (HOOK) dbg_skip = __popcll(__ballot(todo));
             }
@@ -987,11 +1031,14 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 5; j++) same = same && ((int32_t)(uint32_t)(best.key[j] & 0xffffffffu) == pidx[j]);
         if (!same) {
+            if (full) {
 #pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const v4f o = { best.x[j], best.y[j], best.z[j], __int_as_float(full ? (int32_t)(uint32_t)(best.key[j] & 0xffffffffu) : -1) };
-                prevp[(size_t)j * nq + i] = o;
+                for (int j = 0; j < 5; j++) {
+                    const v4f o = { best.x[j], best.y[j], best.z[j], __int_as_float((int32_t)(uint32_t)(best.key[j] & 0xffffffffu)) };
+                    prevp[(size_t)j * nq + i] = o;
+                }
             }
+            G(cp->prior_valid)[i] = full ? 1 : 0;
         }
 
         const float d2_4 = __uint_as_float((uint32_t)(best.key[4] >> 32));
@@ -1006,9 +1053,9 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
             const auto pstate = G(cp->plane_state);
             float pa, pb, pc, pd;
             bool planeValid;
-            const int pst = (same && !(ablate & 32)) ? pstate[i] : 0;
+            const int pst = (same && !(ablate & 32)) ? pst_early : 0;
             if (pst != 0) {
-                const v4f pl = pcache[i];
+                const v4f pl = pl_early;
                 pa = pl.x; pb = pl.y; pc = pl.z; pd = pl.w; planeValid = (pst == 1);
             } else {
                 float qr[5][3];
@@ -1043,9 +1090,8 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         }
 
         if (keep) {
-            const float sc[6] = { st->sc[0], st->sc[1], st->sc[2], st->sc[3], st->sc[4], st->sc[5] };
             float row[6], rhs;
-            jacobian_row(sc, px, py, pz, cf, row, rhs);
+            jacobian_row(sc6, px, py, pz, cf, row, rhs);
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; a++)
@@ -1100,7 +1146,9 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     }
     __syncthreads();
     if (tid < kAcc) {
-        const double s = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+        double s = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < NW; w++) s += red[w][tid];
         G(cp->partials)[(size_t)blockIdx.x * kAcc + tid] = s;
     }
 #undef S2M_LAP
@@ -1407,11 +1455,16 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
 {
     const auto st = G(cp->state);
     const auto trace = G(cp->trace);
-    if (mode == 0 && st->done) return;
+    // loop state, fetched up front so that it is in flight together with the partial sums
+    const int done0 = st->done, degen0 = st->isDegenerate;
+    float pose0[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose0[k] = st->pose[k];
+    if (mode == 0 && done0) return;
 
     __shared__ double part[kFinThreads / 32][32];
     __shared__ double tot[32];
-    __shared__ float sAtA[36], sAtB[6], sA[6][8], sv[8], sX[8], sPose[8], sSC[8];
+    __shared__ float sAtA[36], sAtB[6], sA[6][8], sv[8], sX[8], sPose[8];
     __shared__ float eA[6][6], eV[6][6], eVi[6][6], eV2[6][6], eW[6];
     __shared__ int eR[6], eC[6];
 
@@ -1420,7 +1473,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
     double s = 0.0;
     if (col < kAcc) {
         const auto P = G((const double*)cp->partials);
-        const int nb = cp->nblocks;
+        const int nb = min(cp->nblocks, (*G(cp->n_waves) + (kBlock / 64) - 1) / (kBlock / 64));   // active workgroups
         for (int b0 = grp; b0 < nb; b0 += 16 * NG) {    // 16 independent loads in flight per lane
             double v[16];
 #pragma unroll
@@ -1458,7 +1511,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
             s2m_iter_trace tr;
             tr.n_sel = n_sel; tr.stepped = 0; tr.deltaR = 0.0f; tr.deltaT = 0.0f;
 #pragma unroll
-            for (int k = 0; k < 6; k++) { tr.pose[k] = st->pose[k]; tr.delta[k] = 0.0f; }
+            for (int k = 0; k < 6; k++) { tr.pose[k] = pose0[k]; tr.delta[k] = 0.0f; }
             st->stalled = 1; st->done = 1;              // the remaining iterations repeat this no-op
             st->iters_run = cp->max_iter;
             store_trace(trace + iter, tr);
@@ -1508,8 +1561,8 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
     if (t == 0) {
         float X[6], pose[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) { X[k] = sX[k]; pose[k] = st->pose[k]; }
-        if (st->isDegenerate) {                         // :1266-1271
+        for (int k = 0; k < 6; k++) { X[k] = sX[k]; pose[k] = pose0[k]; }
+        if ((iter == 0) ? (st->isDegenerate != 0) : (degen0 != 0)) {   // :1266-1271 (iteration 0: just decided by wave 1)
             float X2[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) X2[k] = X[k];
@@ -1530,24 +1583,11 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
 #pragma unroll
         for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; }
     }
-    __syncthreads();
-    // ---- lanes 0..2: sin/cos of yaw, pitch, roll for the next launch (:348-351, :1170-1175), in
-    // fp64 rounded once to fp32 (device sinf/cosf are a few ulp off libm's; the double-rounded value
-    // agrees with a correctly rounded fp32 libm result)
-    if (t < 3) {
-        double sn, cs;
-        sincos((double)sPose[2 - t], &sn, &cs);         // t=0: yaw, 1: pitch, 2: roll
-        sSC[2 * t] = (float)sn; sSC[2 * t + 1] = (float)cs;
-    }
-    __syncthreads();
     if (t == 0) {
-        const float B = sSC[0], A = sSC[1], D = sSC[2], C = sSC[3], F = sSC[4], E = sSC[5];
-        const float DE = D * E, DF = D * F;
-        st->T[0] = A * C; st->T[1] = A * DF - B * E; st->T[2]  = B * F + A * DE; st->T[3]  = sPose[3];
-        st->T[4] = B * C; st->T[5] = A * E + B * DF; st->T[6]  = B * DE - A * F; st->T[7]  = sPose[4];
-        st->T[8] = -D;    st->T[9] = C * F;          st->T[10] = C * E;          st->T[11] = sPose[5];
+        // the next launch rebuilds its transform from this pose (k_register prologue)
 #pragma unroll
-        for (int k = 0; k < 6; k++) { st->sc[k] = sSC[k]; st->pose[k] = sPose[k]; }
+        for (int k = 0; k < 6; k++) st->pose[k] = sPose[k];
+        st->T_valid = 0;
         store_trace(trace + iter, tr);
         st->iters_run = iter + 1;
         if (conv && !st->converged) st->converged = 1;

@@ -7,11 +7,11 @@
 
 namespace s2m {
 
-constexpr int kBlock = 256;            // threads per workgroup of the registration kernel (4 waves)
+constexpr int kBlock = 512;            // threads per workgroup of the registration kernel (8 waves: fewer partial rows for k_finalize)
 constexpr int kAcc = 28;               // 21 upper-triangular JtJ + 6 Jtr + 1 correspondence count
-constexpr int kFinThreads = 512;       // finalize kernel workgroup
+constexpr int kFinThreads = 1024;      // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
-constexpr int kBlocksQuantum = 16;     // graph cache key granularity (workgroups)
+constexpr int kBlocksQuantum = 8;      // graph cache key granularity (workgroups)
 
 // Uniform search grid over the map: cell edge E >= sqrt(gate_sq)*(1+2^-10), so the 3x3x3
 // neighbourhood of a query's cell holds every map point with fp32 d2 < gate_sq.
@@ -37,6 +37,7 @@ struct DevState {
     int32_t iters_run;
     int32_t n_sel_last;
     int32_t stalled;      // n_sel < min_corr: every further iteration is the same no-op
+    int32_t T_valid;      // 1: T/sc were set by the host for this pose; 0: k_register rebuilds them from pose
 };
 
 // Everything a kernel needs, in device memory so a captured graph stays valid when
@@ -47,7 +48,8 @@ struct DevCtx {
     const int32_t* cell_start;    // [ncells+1]
     const float* qx; const float* qy; const float* qz;   // [n_q] lidar-frame scan, SoA, locality-sorted
     const int32_t* qperm;         // [n_q] sorted position -> original scan index
-    float4*  prevp;               // [5][n_q] previous launch's neighbours per sorted scan point: x,y,z, map index (-1 = none)
+    float4*  prevp;               // [5][n_q] previous launch's neighbours per sorted scan point: x,y,z, map index
+    int32_t* prior_valid;         // [n_q] 1 if prevp holds 5 neighbours of the current map for this point
     float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to prev5's tuple
     int32_t* plane_state;         // [n_q] 0 none, 1 plane passed the inlier test, 2 plane failed it
     int32_t n_q, n_m, nblocks;

@@ -91,7 +91,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_normal_eq.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_int32)]
     L.s2m_last_timing.argtypes = [vp, fp, fp, fp]
     L.s2m_time_iteration_kernel.argtypes = [vp, fp, C.c_int, fp]
-    L.s2m_debug_wave_profile.argtypes = [vp, fp, C.POINTER(C.c_uint64), C.c_size_t]
+    L.s2m_debug_wave_profile.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint64), C.c_size_t]
     L.s2m_make_scancontext.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     if path is None:
         _LIB = L
@@ -249,12 +249,12 @@ class MapOptimizationS2M:
         self._check(self.lib.s2m_time_iteration_kernel(self.h, _fp(p), reps, C.byref(ms)), "s2m_time_iteration_kernel")
         return ms.value
 
-    def wave_profile(self, pose) -> np.ndarray:
+    def wave_profile(self, pose, launches: int = 3) -> np.ndarray:
         """Diagnostics: (n_waves, 16) uint64 per-wave stamps/stats of one k_register pass."""
         p = np.ascontiguousarray(pose, np.float32)
         cap = (self.laserCloudSurfLastDSNum + 15) // 16 + 256
         out = np.zeros((cap, 16), np.uint64)
-        n = self.lib.s2m_debug_wave_profile(self.h, _fp(p), out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
+        n = self.lib.s2m_debug_wave_profile(self.h, _fp(p), launches, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
         if n < 0:
             self._check(n, "s2m_debug_wave_profile")
         return out[:n]

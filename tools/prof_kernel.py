@@ -12,7 +12,23 @@ eng.setScan(synth.to_xyzi(cfg["scan"]))
 ms = eng.time_iteration_kernel(cfg["pose_init"], max(1, reps // 30))
 print("ablate=%s k_register %.2f us (mean over full LM loops)" % (os.environ.get("S2M_ABLATE", "0"), ms * 1e3))
 if os.environ.get("S2M_WAVES"):
-    w = eng.wave_profile(cfg["pose_init"]).astype(np.int64)
+    mode = os.environ.get("S2M_WAVES")
+    if mode == "iter1":      # launch 1 of a real loop: prior recorded at pose_init, pose after the first LM step
+        eng.setScan(synth.to_xyzi(cfg["scan"]))
+        eng.surfOptimization(cfg["pose_init"])
+        eng.transformTobeMapped = cfg["pose_init"].copy()
+        p1 = np.array(s2m.MapOptimizationS2M.trace(eng)[0].pose if False else cfg["pose_init"], np.float32)
+        # one LM step on the oracle-free path: take it from the engine's own trace of a 1-iteration run
+        e1 = s2m.MapOptimizationS2M(early_exit=0, max_iter=1)
+        e1.setInputCloud(synth.to_xyzi(cfg["map"])); e1.setScan(synth.to_xyzi(cfg["scan"]))
+        e1.transformTobeMapped = cfg["pose_init"].copy(); r1 = e1.scan2MapOptimization(); p1 = np.array(r1.pose, np.float32); e1.close()
+        print("pose after launch 0:", p1 - cfg["pose_init"])
+        w = eng.wave_profile(p1, launches=1).astype(np.int64)
+    elif mode == "iter0":
+        eng.setScan(synth.to_xyzi(cfg["scan"]))
+        w = eng.wave_profile(cfg["pose_init"], launches=1).astype(np.int64)
+    else:
+        w = eng.wave_profile(cfg["pose_init"]).astype(np.int64)
     w = w[w[:, 0] > 0]
     t0 = w[:, 0].min()
     search, plane, red = (w[:, 1] - w[:, 0]) / 100.0, (w[:, 2] - w[:, 1]) / 100.0, (w[:, 3] - w[:, 2]) / 100.0
