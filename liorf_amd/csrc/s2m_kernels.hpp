@@ -656,7 +656,7 @@ __device__ __forceinline__ constexpr int run_dy(int k) { return (int)((139617u >
 __device__ __forceinline__ constexpr int run_dz(int k) { return (int)((164373u >> (2 * k)) & 3u) - 1; }
 
 template <bool HOOK>
-__global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ cp)
+__global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict__ cp)
 {
     constexpr int NW = kBlock / 64;
     const auto st = G((const DevState*)cp->state);
@@ -665,8 +665,8 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
     if (HOOK) { tk_start = wall_clock64(); tk = tk_start; }
 #define S2M_LAP(acc) do { if (HOOK) { const unsigned long long n__ = wall_clock64(); (acc) += n__ - tk; tk = n__; } } while (0)
 
-    __shared__ v4f     s_pts[NW][kTilePts];
-    __shared__ int32_t s_run[NW][18][64];           // gather path: this lane's 9 (start, end) pairs
+    __shared__ v4f     s_pts[NW][kTilePts];          // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
+    static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
     __shared__ double  red[NW][32];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -920,7 +920,7 @@ __global__ __launch_bounds__(kBlock) void k_register(const DevCtx* __restrict__ 
         if (__ballot(glanes)) {
             if (HOOK) dbg_mode = tile ? 3 : 2;
             // ---- gather: run bounds of all 9 rows first (independent loads, kept in LDS), then the runs
-            int32_t (*lrun)[64] = s_run[wave];
+            int32_t (*lrun)[64] = reinterpret_cast<int32_t (*)[64]>(s_pts[wave]);
             if (glanes && !(ablate & 1)) {
                 int rs[9], re[9];
 #pragma unroll
