@@ -70,6 +70,7 @@ struct s2m_context {
     bool use_graph = true;
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
     float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
+    int base_parts = 1;
     bool opt_pending = false;
     bool scan_timing_pending = false;
     int pending_skipped = 0;
@@ -239,7 +240,11 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     // wave table capacity: every 64-point chunk plus a 50 % budget of extra waves for split chunks
     const int n_chunks = (int)((n + 63) / 64);
     constexpr int NW = kBlock / 64;
-    int nblocks = (n_chunks + n_chunks / 2 + NW - 1) / NW;
+    // how finely to cut when the scan alone cannot fill the GPU (~2048 co-resident waves): 1, 2, 4 or 8
+    int base_parts = 1;
+    while (base_parts < 8 && n_chunks * base_parts * 2 <= 2048) base_parts *= 2;
+    h->base_parts = base_parts;
+    int nblocks = (n_chunks * base_parts + n_chunks / 2 + NW - 1) / NW;
     nblocks = ((nblocks + kBlocksQuantum - 1) / kBlocksQuantum) * kBlocksQuantum;
     if (nblocks == 0) nblocks = kBlocksQuantum;
     h->hctx.nblocks = nblocks;
@@ -291,7 +296,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
         if ((rc = ensure(h, h->wave_table, sizeof(int2) * (size_t)capacity))) return rc;
         if ((rc = ensure(h, h->n_waves, 64))) return rc;
         hipLaunchKernelGGL(k_chunk_parts, dim3((n_chunks + 3) / 4), dim3(256), 0, h->stream, (const float*)h->qx.as<float>(),
-                           (const float*)h->qy.as<float>(), (const float*)h->qz.as<float>(), (int)n, n_chunks, h->chunk_parts.as<int32_t>());
+                           (const float*)h->qy.as<float>(), (const float*)h->qz.as<float>(), (int)n, n_chunks, h->base_parts, h->chunk_parts.as<int32_t>());
         hipLaunchKernelGGL(k_chunk_table, dim3(1), dim3(1024), 0, h->stream, (const int32_t*)h->chunk_parts.as<int32_t>(), (int)n, n_chunks,
                            capacity, h->wave_table.as<int2>(), h->n_waves.as<int32_t>());
         S2M_HIP(h, hipGetLastError());

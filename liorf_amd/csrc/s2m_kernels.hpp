@@ -281,10 +281,10 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
 // Work-proportional wave assignment.  The sorted scan is cut into chunks of 64 points; a chunk
 // whose points spread over a large box (sparse far field, tall structures) would make its wave
 // stage and sweep a large map tile, and the slowest wave sets the kernel time.  Such chunks are
-// given to 2 or 4 waves (32 / 16 points each: tighter boxes, run in parallel).  The extent is
+// given to 2, 4 or 8 waves (32 / 16 / 8 points each: tighter boxes, run in parallel).  The extent is
 // measured in the lidar frame - a rigid transform does not change it.
 __global__ __launch_bounds__(256) void k_chunk_parts(const float* __restrict__ qx, const float* __restrict__ qy,
-                                                     const float* __restrict__ qz, int n, int n_chunks,
+                                                     const float* __restrict__ qz, int n, int n_chunks, int base_parts,
                                                      int32_t* __restrict__ parts)
 {
     const int lane = threadIdx.x & 63;
@@ -311,34 +311,34 @@ __global__ __launch_bounds__(256) void k_chunk_parts(const float* __restrict__ q
             const float vol = (mx[0] - mn[0] + 3.0f) * (mx[1] - mn[1] + 3.0f) * (mx[2] - mn[2] + 3.0f);
             p = vol > 700.0f ? 4 : (vol > 180.0f ? 2 : 1);
         }
-        parts[c] = p;
+        // a small scan leaves most of the GPU idle: cut every chunk finer (base_parts) and large ones finer still
+        parts[c] = min(8, max(p, base_parts) * ((p > 1 && base_parts > 1) ? 2 : 1));
     }
 }
 
 // one workgroup: exclusive scan of parts[] and emission of the wave table {first point, count}.
 // The table has room for every chunk unsplit plus a budget of extra waves; if the wishes exceed
-// it they are scaled back uniformly (4 -> 2, then everything -> 1), so the table never overflows.
+// it they are scaled back uniformly (cap 8 -> 4 -> 2 -> 1), so the table never overflows.
 __global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict__ parts, int n, int n_chunks, int capacity,
                                                       int2* __restrict__ table, int32_t* __restrict__ n_waves_out)
 {
     __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s, tot_s[2];
+    __shared__ int32_t carry_s, tot_s[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // pass A: total waves wished for, at full wishes and with 4 -> 2
-    int t0 = 0, t1 = 0;
-    for (int c = threadIdx.x; c < n_chunks; c += 1024) { const int p = parts[c]; t0 += p; t1 += min(p, 2); }
+    // pass A: total waves wished for when parts are capped at 8, 4, 2
+    int t8 = 0, t4 = 0, t2 = 0;
+    for (int c = threadIdx.x; c < n_chunks; c += 1024) { const int p = parts[c]; t8 += p; t4 += min(p, 4); t2 += min(p, 2); }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { t0 += __shfl_xor(t0, off, 64); t1 += __shfl_xor(t1, off, 64); }
-    if (threadIdx.x == 0) { carry_s = 0; tot_s[0] = 0; tot_s[1] = 0; }
+    for (int off = 32; off > 0; off >>= 1) { t8 += __shfl_xor(t8, off, 64); t4 += __shfl_xor(t4, off, 64); t2 += __shfl_xor(t2, off, 64); }
+    if (threadIdx.x == 0) { carry_s = 0; tot_s[0] = 0; tot_s[1] = 0; tot_s[2] = 0; }
     __syncthreads();
-    if (lane == 0) { atomicAdd(&tot_s[0], t0); atomicAdd(&tot_s[1], t1); }
+    if (lane == 0) { atomicAdd(&tot_s[0], t8); atomicAdd(&tot_s[1], t4); atomicAdd(&tot_s[2], t2); }
     __syncthreads();
-    const int level = (tot_s[0] <= capacity) ? 0 : ((tot_s[1] <= capacity) ? 1 : 2);
+    const int pcap = (tot_s[0] <= capacity) ? 8 : ((tot_s[1] <= capacity) ? 4 : ((tot_s[2] <= capacity) ? 2 : 1));
     // pass B: scan and emit
     for (int base = 0; base < n_chunks; base += 1024) {
         const int c = base + threadIdx.x;
-        int p = (c < n_chunks) ? parts[c] : 0;
-        if (level == 1) p = min(p, 2); else if (level == 2) p = min(p, 1);
+        const int p = (c < n_chunks) ? min(parts[c], pcap) : 0;
         int incl = p;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
