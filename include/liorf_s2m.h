@@ -40,6 +40,7 @@ extern "C" {
 #define S2M_ERR_HIP           -3   /* a HIP runtime call failed (see s2m_last_error) */
 #define S2M_ERR_NO_SCAN       -4   /* *_resident call without s2m_set_scan          */
 #define S2M_ERR_CAPACITY      -5   /* grid / buffer limit exceeded                   */
+#define S2M_WARN_LEAF_TOO_SMALL 1   /* voxel filter: PCL's "leaf size is too small" case, output = input */
 
 /* ScanContext descriptor shape (reference include/Scancontext.h:82-84) */
 #define S2M_SC_NUM_RING    20
@@ -174,6 +175,42 @@ int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, floa
  * (1 LDS tile, 2 gather), box rows, points visited, 0; ticks spent in prior+box / row marking /
  * (unused) / staging / search; 3 spare. Returns the number of waves written (<= cap_waves). */
 int  s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint64_t* out, size_t cap_waves);
+
+/* ---- The voxel-grid stages either side of the path ----------
+ * pcl::VoxelGrid<pcl::PointXYZI>::applyFilter with the reference's settings (all fields averaged,
+ * no minimum point count): one output record {centroid x, y, z, 1.0f, mean intensity, 0...} per occupied
+ * voxel, in ascending voxel-index order like PCL. Input records carry intensity at byte 16 when
+ * stride_bytes >= 20 (pcl::PointXYZI). Points with a non-finite coordinate are skipped. Within a voxel the
+ * points are summed in ascending input order (PCL's unstable std::sort leaves that order unspecified).
+ * `cap` is the capacity of `out` in records; *n_out is always the number of voxels, and a result that does
+ * not fit returns S2M_ERR_CAPACITY after writing the first `cap` records. S2M_WARN_LEAF_TOO_SMALL (> 0)
+ * reports PCL's index-overflow case, where the output is the unfiltered input. */
+
+/* downSizeFilter*.setInputCloud(cloud); .filter(out) for a host cloud (reference :1064-1065, :1037-1038). */
+int  s2m_voxel_downsample(s2m_handle h, const void* pts, size_t n, size_t stride_bytes, float leaf,
+                          void* out, size_t out_stride_bytes, size_t cap, size_t* n_out);
+/* Same with both clouds in device memory (no host copies; returns after the handle's stream has drained). */
+int  s2m_voxel_downsample_device(s2m_handle h, const void* d_pts, size_t n, size_t stride_bytes, float leaf,
+                                 void* d_out, size_t out_stride_bytes, size_t cap, size_t* n_out);
+/* downsampleCurrentScan() (reference :1061-1067) fused with s2m_set_scan: filters laserCloudSurfLast
+ * (host records, or device records when on_device != 0) with leaf mappingSurfLeafSize and installs the result
+ * as the scan of the next s2m_optimize_resident / s2m_optimize_launch. If cap > 0 the filtered cloud
+ * (laserCloudSurfLastDS, which the node later stores as the key frame's cloud) is also copied to host `out`. */
+int  s2m_downsample_scan(s2m_handle h, const void* pts, size_t n, size_t stride_bytes, int on_device, float leaf,
+                         void* out, size_t out_stride_bytes, size_t cap, size_t* n_out);
+/* extractCloud() (reference :1014-1039) after the key-frame selection, fused with s2m_set_map: for the
+ * chosen key frames f = 0..n_frames-1, transformPointCloud(frames[f], pose f) (:310-329; poses_xyzrpy holds
+ * {x, y, z, roll, pitch, yaw} of each PointTypePose), concatenated in that order, filtered with leaf
+ * surroundingKeyframeMapLeafSize, and installed as the local surf map (the reference's kd-tree build,
+ * :1302). frames[] are host buffers, or device buffers when on_device != 0 (a device-resident key-frame
+ * store replaces the reference's laserCloudMapContainer cache: re-transforming is cheaper than caching).
+ * If cap > 0 the filtered map (laserCloudSurfFromMapDS) is also copied to host `out`. */
+int  s2m_extract_cloud(s2m_handle h, int n_frames, const void* const* frames, const size_t* frame_sizes,
+                       size_t stride_bytes, int on_device, const float* poses_xyzrpy, float leaf,
+                       void* out, size_t out_stride_bytes, size_t cap, size_t* n_out);
+/* transformPointCloud(cloudIn, transformIn) (reference :310-329) for one host cloud; out holds n records. */
+int  s2m_transform_cloud(s2m_handle h, const void* pts, size_t n, size_t stride_bytes, const float pose_xyzrpy[6],
+                         void* out, size_t out_stride_bytes);
 
 /* ---- ScanContext descriptor (BASELINE config 5) ------------------------- */
 /* SCManager::makeScancontext + makeRingkeyFromScancontext

@@ -19,6 +19,7 @@
 
 #include "s2m_host_math.hpp"
 #include "s2m_kernels.hpp"
+#include "s2m_voxel.hpp"
 
 using namespace s2m;
 
@@ -48,6 +49,9 @@ struct s2m_context {
     DevBuf raw_scan, qx, qy, qz, qperm, prevp, prior_valid, plane_cache, plane_state, chunk_parts, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
+    // voxel-grid stages that feed the path (section 8(f) F1/F2): staging for host clouds, transformed key frames, filtered clouds
+    DevBuf vox_in, vox_out, frames_xf, scan_ds, map_ds;
+    VoxWorkspace* vox = nullptr;
 
     DevCtx hctx{};
     bool ctx_dirty = true;
@@ -58,7 +62,6 @@ struct s2m_context {
     DevState* h_state = nullptr;       // [2]: [0] upload, [1] download
     s2m_iter_trace* h_trace = nullptr; // [kMaxIter]
     uint32_t* h_mm = nullptr;          // [6]
-    DevCtx* h_ctx_pin = nullptr;
     double* h_sc = nullptr;            // [1200 + 20]
 
     // state that persists across scans in the reference node (:139-140)
@@ -347,7 +350,7 @@ int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "hipStreamEndCapture", e);
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    hipGraphDestroy(graph);
+    (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "hipGraphInstantiate", e);
     h->graphs[nblocks] = exec;
     *out = exec;
@@ -376,6 +379,35 @@ int launch_loop(s2m_context* h)
     }
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    return S2M_OK;
+}
+
+constexpr size_t kDsStride = 32;       // filtered clouds are kept as pcl::PointXYZI records
+
+int check_leaf(s2m_context* h, float leaf)
+{
+    if (!(leaf > 0.0f) || !std::isfinite(leaf)) return fail(h, S2M_ERR_INVALID_ARG, "leaf size must be positive and finite");
+    return S2M_OK;
+}
+
+// VoxelGrid of a device cloud into `dst` (grown to hold one record per input point, the worst case).
+int voxel_into(s2m_context* h, const unsigned char* d_in, size_t n, size_t stride, float leaf, DevBuf& dst, VoxResult* res)
+{
+    int rc = ensure(h, dst, kDsStride * (n ? n : 1));
+    if (rc) return rc;
+    hipError_t e = vox_downsample(h->vox, h->stream, d_in, n, stride, leaf, dst.as<unsigned char>(), kDsStride, n, res);
+    if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "voxel grid filter", e);
+    return S2M_OK;
+}
+
+// strided device records -> caller's host buffer (min(n, cap) records)
+int download_records(s2m_context* h, const DevBuf& src, size_t n, void* out, size_t out_stride, size_t cap)
+{
+    const size_t m = n < cap ? n : cap;
+    if (m == 0 || !out) return S2M_OK;
+    S2M_HIP(h, hipMemcpy2DAsync(out, out_stride, src.p, kDsStride, out_stride < kDsStride ? out_stride : kDsStride, m,
+                                hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
     return S2M_OK;
 }
 
@@ -436,13 +468,14 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (hipHostMalloc((void**)&h->h_state, sizeof(DevState) * 2) != hipSuccess) return bail(S2M_ERR_HIP);
     if (hipHostMalloc((void**)&h->h_trace, sizeof(s2m_iter_trace) * kMaxIter) != hipSuccess) return bail(S2M_ERR_HIP);
     if (hipHostMalloc((void**)&h->h_mm, 64) != hipSuccess) return bail(S2M_ERR_HIP);
-    if (hipHostMalloc((void**)&h->h_ctx_pin, sizeof(DevCtx)) != hipSuccess) return bail(S2M_ERR_HIP);
     if (hipHostMalloc((void**)&h->h_sc, sizeof(double) * 1220) != hipSuccess) return bail(S2M_ERR_HIP);
     if (ensure(h, h->state, sizeof(DevState)) || ensure(h, h->trace, sizeof(s2m_iter_trace) * kMaxIter) ||
         ensure(h, h->dctx, sizeof(DevCtx)) || ensure(h, h->mm, 64) ||
         ensure(h, h->partials, sizeof(double) * kAcc * kBlocksQuantum) ||
         ensure(h, h->sc_bins, sizeof(uint32_t) * 1200) || ensure(h, h->sc_out, sizeof(double) * 1220))
         return bail(S2M_ERR_HIP);
+
+    if (!(h->vox = vox_create())) return bail(S2M_ERR_HIP);
 
     memset(&h->hctx, 0, sizeof(h->hctx));
     h->hctx.nblocks = kBlocksQuantum;
@@ -464,25 +497,26 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
 int s2m_destroy(s2m_handle h)
 {
     if (!h) return S2M_OK;
-    hipSetDevice(h->device);
-    if (h->stream) hipStreamSynchronize(h->stream);
-    for (auto& kv : h->graphs) hipGraphExecDestroy(kv.second);
-    for (hipEvent_t e : h->iter_events) hipEventDestroy(e);
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
                        &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->prior_valid, &h->plane_cache, &h->plane_state, &h->chunk_parts, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
-                       &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out };
-    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
-    if (h->h_state) hipHostFree(h->h_state);
-    if (h->h_trace) hipHostFree(h->h_trace);
-    if (h->h_mm) hipHostFree(h->h_mm);
-    if (h->h_ctx_pin) hipHostFree(h->h_ctx_pin);
-    if (h->h_sc) hipHostFree(h->h_sc);
-    if (h->ev_a) hipEventDestroy(h->ev_a);
-    if (h->ev_b) hipEventDestroy(h->ev_b);
-    if (h->ev_c) hipEventDestroy(h->ev_c);
-    if (h->ev_d) hipEventDestroy(h->ev_d);
-    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
+                       &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out,
+                       &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds };
+    for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
+    vox_destroy(h->vox);
+    if (h->h_state) (void)hipHostFree(h->h_state);
+    if (h->h_trace) (void)hipHostFree(h->h_trace);
+    if (h->h_mm) (void)hipHostFree(h->h_mm);
+    if (h->h_sc) (void)hipHostFree(h->h_sc);
+    if (h->ev_a) (void)hipEventDestroy(h->ev_a);
+    if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->ev_c) (void)hipEventDestroy(h->ev_c);
+    if (h->ev_d) (void)hipEventDestroy(h->ev_d);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return S2M_OK;
 }
@@ -719,6 +753,146 @@ int s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float
     }
     *ms_per_launch = (float)(total_ms / (double)launches);
     return S2M_OK;
+}
+
+// ---- section 8(f) rows F2 / F1: the voxel-grid stages either side of the path ------------------------
+
+static int voxel_downsample_impl(s2m_handle h, const void* pts, size_t n, size_t stride_bytes, float leaf,
+                                 void* out, size_t out_stride_bytes, size_t cap, size_t* n_out, bool on_device)
+{
+    int rc = check_records(h, pts, n, stride_bytes);
+    if (rc) return rc;
+    if ((rc = check_leaf(h, leaf))) return rc;
+    if (!n_out || (cap > 0 && !out) || out_stride_bytes < 12 || (out_stride_bytes & 3))
+        return fail(h, S2M_ERR_INVALID_ARG, "bad output buffer");
+    *n_out = 0;
+    if (n == 0) return S2M_OK;
+    S2M_HIP(h, hipSetDevice(h->device));
+    VoxResult res;
+    if (on_device) {
+        hipError_t e = vox_downsample(h->vox, h->stream, static_cast<const unsigned char*>(pts), n, stride_bytes, leaf,
+                                      static_cast<unsigned char*>(out), out_stride_bytes, cap, &res);
+        if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "voxel grid filter", e);
+    } else {
+        if ((rc = ensure(h, h->vox_in, n * stride_bytes))) return rc;
+        S2M_HIP(h, hipMemcpyAsync(h->vox_in.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
+        if ((rc = voxel_into(h, h->vox_in.as<unsigned char>(), n, stride_bytes, leaf, h->vox_out, &res))) return rc;
+        if ((rc = download_records(h, h->vox_out, res.n_out, out, out_stride_bytes, cap))) return rc;
+    }
+    *n_out = res.n_out;
+    if (res.n_out > cap) return fail(h, S2M_ERR_CAPACITY, "output buffer too small for the filtered cloud");
+    return res.leaf_too_small ? S2M_WARN_LEAF_TOO_SMALL : S2M_OK;
+}
+
+int s2m_voxel_downsample(s2m_handle h, const void* pts, size_t n, size_t stride_bytes, float leaf,
+                         void* out, size_t out_stride_bytes, size_t cap, size_t* n_out)
+{ return voxel_downsample_impl(h, pts, n, stride_bytes, leaf, out, out_stride_bytes, cap, n_out, false); }
+
+int s2m_voxel_downsample_device(s2m_handle h, const void* d_pts, size_t n, size_t stride_bytes, float leaf,
+                                void* d_out, size_t out_stride_bytes, size_t cap, size_t* n_out)
+{ return voxel_downsample_impl(h, d_pts, n, stride_bytes, leaf, d_out, out_stride_bytes, cap, n_out, true); }
+
+int s2m_downsample_scan(s2m_handle h, const void* pts, size_t n, size_t stride_bytes, int on_device, float leaf,
+                        void* out, size_t out_stride_bytes, size_t cap, size_t* n_out)
+{
+    int rc = check_records(h, pts, n, stride_bytes);
+    if (rc) return rc;
+    if ((rc = check_leaf(h, leaf))) return rc;
+    if (!n_out || (cap > 0 && (!out || out_stride_bytes < 12 || (out_stride_bytes & 3))))
+        return fail(h, S2M_ERR_INVALID_ARG, "bad output buffer");
+    *n_out = 0;
+    S2M_HIP(h, hipSetDevice(h->device));
+    VoxResult res;
+    if (n > 0) {
+        const unsigned char* d_in = static_cast<const unsigned char*>(pts);
+        if (!on_device) {
+            if ((rc = ensure(h, h->vox_in, n * stride_bytes))) return rc;
+            S2M_HIP(h, hipMemcpyAsync(h->vox_in.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
+            d_in = h->vox_in.as<unsigned char>();
+        }
+        if ((rc = voxel_into(h, d_in, n, stride_bytes, leaf, h->scan_ds, &res))) return rc;
+    }
+    *n_out = res.n_out;
+    // laserCloudSurfLastDS stays on the device as the registration's scan; the host copy is for the key-frame store
+    if ((rc = set_scan_impl(h, h->scan_ds.p, res.n_out, kDsStride, true))) return rc;
+    if (cap > 0 && (rc = download_records(h, h->scan_ds, res.n_out, out, out_stride_bytes, cap))) return rc;
+    if (cap > 0 && res.n_out > cap) return fail(h, S2M_ERR_CAPACITY, "output buffer too small for the filtered scan");
+    return res.leaf_too_small ? S2M_WARN_LEAF_TOO_SMALL : S2M_OK;
+}
+
+int s2m_extract_cloud(s2m_handle h, int n_frames, const void* const* frames, const size_t* frame_sizes,
+                      size_t stride_bytes, int on_device, const float* poses_xyzrpy, float leaf,
+                      void* out, size_t out_stride_bytes, size_t cap, size_t* n_out)
+{
+    if (!h) return S2M_ERR_INVALID_ARG;
+    if (n_frames < 0 || (n_frames > 0 && (!frames || !frame_sizes || !poses_xyzrpy)))
+        return fail(h, S2M_ERR_INVALID_ARG, "null key-frame table");
+    int rc = check_leaf(h, leaf);
+    if (rc) return rc;
+    if (!n_out || (cap > 0 && (!out || out_stride_bytes < 12 || (out_stride_bytes & 3))))
+        return fail(h, S2M_ERR_INVALID_ARG, "bad output buffer");
+    *n_out = 0;
+    size_t total = 0;
+    for (int f = 0; f < n_frames; f++) {
+        if ((rc = check_records(h, frames[f], frame_sizes[f], stride_bytes))) return rc;
+        total += frame_sizes[f];
+        if (total > (size_t)0x3fffffff) return fail(h, S2M_ERR_CAPACITY, "too many points");
+    }
+    S2M_HIP(h, hipSetDevice(h->device));
+    VoxResult res;
+    std::vector<int32_t> offsets((size_t)n_frames + 1, 0);
+    std::vector<float> T((size_t)n_frames * 12);
+    std::vector<const unsigned char*> src((size_t)n_frames, nullptr);
+    if (total > 0) {
+        if (!on_device && (rc = ensure(h, h->vox_in, total * stride_bytes))) return rc;
+        for (int f = 0; f < n_frames; f++) {
+            offsets[f + 1] = offsets[f] + (int32_t)frame_sizes[f];
+            // transCur = pcl::getTransformation(x, y, z, roll, pitch, yaw) of the key pose (:317)
+            const float* p = poses_xyzrpy + 6 * (size_t)f;
+            const float rpyxyz[6] = { p[3], p[4], p[5], p[0], p[1], p[2] };
+            host_pose_to_transform(rpyxyz, &T[12 * (size_t)f], nullptr);
+            if (on_device) src[f] = static_cast<const unsigned char*>(frames[f]);
+            else {
+                unsigned char* dst = h->vox_in.as<unsigned char>() + (size_t)offsets[f] * stride_bytes;
+                if (frame_sizes[f])
+                    S2M_HIP(h, hipMemcpyAsync(dst, frames[f], frame_sizes[f] * stride_bytes, hipMemcpyHostToDevice, h->stream));
+                src[f] = dst;
+            }
+        }
+        if ((rc = ensure(h, h->frames_xf, kDsStride * total))) return rc;
+        hipError_t e = vox_transform_frames(h->vox, h->stream, src.data(), stride_bytes, offsets.data(), T.data(), n_frames,
+                                            h->frames_xf.as<unsigned char>(), kDsStride);
+        if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "key-frame transform", e);
+        if ((rc = voxel_into(h, h->frames_xf.as<unsigned char>(), total, kDsStride, leaf, h->map_ds, &res))) return rc;
+    }
+    *n_out = res.n_out;
+    // laserCloudSurfFromMapDS becomes the search index (the reference's kdtree->setInputCloud, :1302)
+    if ((rc = set_map_impl(h, h->map_ds.p, res.n_out, kDsStride, true))) return rc;
+    if (cap > 0 && (rc = download_records(h, h->map_ds, res.n_out, out, out_stride_bytes, cap))) return rc;
+    if (cap > 0 && res.n_out > cap) return fail(h, S2M_ERR_CAPACITY, "output buffer too small for the local map");
+    return res.leaf_too_small ? S2M_WARN_LEAF_TOO_SMALL : S2M_OK;
+}
+
+int s2m_transform_cloud(s2m_handle h, const void* pts, size_t n, size_t stride_bytes, const float pose_xyzrpy[6],
+                        void* out, size_t out_stride_bytes)
+{
+    int rc = check_records(h, pts, n, stride_bytes);
+    if (rc) return rc;
+    if (!pose_xyzrpy || (n > 0 && !out) || out_stride_bytes < 12 || (out_stride_bytes & 3))
+        return fail(h, S2M_ERR_INVALID_ARG, "bad pose or output buffer");
+    if (n == 0) return S2M_OK;
+    S2M_HIP(h, hipSetDevice(h->device));
+    if ((rc = ensure(h, h->vox_in, n * stride_bytes))) return rc;
+    if ((rc = ensure(h, h->frames_xf, kDsStride * n))) return rc;
+    S2M_HIP(h, hipMemcpyAsync(h->vox_in.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
+    const float rpyxyz[6] = { pose_xyzrpy[3], pose_xyzrpy[4], pose_xyzrpy[5], pose_xyzrpy[0], pose_xyzrpy[1], pose_xyzrpy[2] };
+    float T[12];
+    host_pose_to_transform(rpyxyz, T, nullptr);
+    const int32_t offsets[2] = { 0, (int32_t)n };
+    const unsigned char* src[1] = { h->vox_in.as<unsigned char>() };
+    hipError_t e = vox_transform_frames(h->vox, h->stream, src, stride_bytes, offsets, T, 1, h->frames_xf.as<unsigned char>(), kDsStride);
+    if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "cloud transform", e);
+    return download_records(h, h->frames_xf, n, out, out_stride_bytes, n);
 }
 
 int s2m_make_scancontext(s2m_handle h, const void* pts, size_t n, size_t stride_bytes,

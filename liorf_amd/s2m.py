@@ -10,7 +10,9 @@ raises immediately.
 from __future__ import annotations
 
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 import numpy as np
 
@@ -28,7 +30,10 @@ ABI_SYMBOLS = [
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
     "s2m_time_iteration_kernel", "s2m_make_scancontext", "s2m_debug_wave_profile",
+    "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
+    "s2m_transform_cloud",
 ]
+S2M_WARN_LEAF_TOO_SMALL = 1
 
 
 class Params(C.Structure):
@@ -63,6 +68,25 @@ class S2MError(RuntimeError):
 _LIB = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  The PyTorch-ROCm wheel ships its own libamdhip64.so (soname
+    libamdhip64.so.7) and looks it up by file name; if libliorf_s2m.so has already pulled in
+    /opt/rocm's copy, a later `import torch` loads a second runtime that sees no GPU.  Loading the
+    wheel's copy first (without importing torch) makes both sides resolve to the same runtime, in
+    either import order.  Without a PyTorch wheel the system runtime is used as linked."""
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(p):
+        C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def load_library(path: str | None = None) -> C.CDLL:
     """Load libliorf_s2m.so and declare the ABI. Raises if the HIP library is missing."""
     global _LIB
@@ -72,6 +96,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     if not os.path.exists(p):
         raise S2MError(f"{p} not found: build it with __graft_entry__.build() "
                        f"(make -C liorf_amd/csrc); there is no CPU fallback")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(p)
     vp, fp = C.c_void_p, C.POINTER(C.c_float)
     L.s2m_version.restype = C.c_char_p
@@ -93,6 +118,13 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_time_iteration_kernel.argtypes = [vp, fp, C.c_int, fp]
     L.s2m_debug_wave_profile.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint64), C.c_size_t]
     L.s2m_make_scancontext.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    szp = C.POINTER(C.c_size_t)
+    for n in ("s2m_voxel_downsample", "s2m_voxel_downsample_device"):
+        getattr(L, n).argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_float, vp, C.c_size_t, C.c_size_t, szp]
+    L.s2m_downsample_scan.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.c_int, C.c_float, vp, C.c_size_t, C.c_size_t, szp]
+    L.s2m_extract_cloud.argtypes = [vp, C.c_int, C.POINTER(vp), szp, C.c_size_t, C.c_int, fp, C.c_float,
+                                    vp, C.c_size_t, C.c_size_t, szp]
+    L.s2m_transform_cloud.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, vp, C.c_size_t]
     if path is None:
         _LIB = L
     return L
@@ -170,6 +202,88 @@ class MapOptimizationS2M:
 
     def setInputCloudDevice(self, d_ptr: int, n: int, stride_bytes: int):
         self._check(self.lib.s2m_set_map_device(self.h, C.c_void_p(d_ptr), n, stride_bytes), "s2m_set_map_device")
+
+    # -- the voxel-grid stages that feed the path -------
+    def _check_voxel(self, rc: int, what: str) -> bool:
+        """True when PCL's "leaf size is too small" case was hit (output = input)."""
+        if rc == S2M_WARN_LEAF_TOO_SMALL:
+            return True
+        self._check(rc, what)
+        return False
+
+    def voxelGrid(self, cloud, leaf: float) -> np.ndarray:
+        """downSizeFilter.setInputCloud(cloud); .filter(out): (m, 8) float32 PointXYZI records."""
+        a, n, st = _records(cloud)
+        out = np.zeros((max(n, 1), 8), np.float32)
+        m = C.c_size_t(0)
+        self.leaf_too_small = self._check_voxel(
+            self.lib.s2m_voxel_downsample(self.h, a.ctypes.data, n, st, leaf, out.ctypes.data, 32, n, C.byref(m)),
+            "s2m_voxel_downsample")
+        return out[:m.value]
+
+    def voxelGridDevice(self, d_in: int, n: int, stride_bytes: int, leaf: float, d_out: int, cap: int) -> int:
+        """Both clouds in HBM (32-byte output records); returns the number of voxels."""
+        m = C.c_size_t(0)
+        self.leaf_too_small = self._check_voxel(
+            self.lib.s2m_voxel_downsample_device(self.h, C.c_void_p(d_in), n, stride_bytes, leaf, C.c_void_p(d_out), 32,
+                                                 cap, C.byref(m)), "s2m_voxel_downsample_device")
+        return m.value
+
+    def downsampleCurrentScan(self, laserCloudSurfLast, leaf: float, readback: bool = True, device_ptr=None):
+        """Reference :1061-1067, fused with setScan: returns laserCloudSurfLastDS (or None if !readback).
+        `device_ptr=(ptr, n, stride_bytes)` filters a cloud that already lives in HBM."""
+        if device_ptr is not None:
+            ptr, n, st = device_ptr
+            src, on_dev = C.c_void_p(ptr), 1
+        else:
+            a, n, st = _records(laserCloudSurfLast)
+            src, on_dev = a.ctypes.data, 0
+        out = np.zeros((max(n, 1), 8), np.float32) if readback else None
+        m = C.c_size_t(0)
+        self.leaf_too_small = self._check_voxel(
+            self.lib.s2m_downsample_scan(self.h, src, n, st, on_dev, leaf, out.ctypes.data if readback else None, 32,
+                                         n if readback else 0, C.byref(m)), "s2m_downsample_scan")
+        self.laserCloudSurfLastDSNum = m.value
+        return out[:m.value] if readback else None
+
+    def extractCloud(self, frames, poses_xyzrpy, leaf: float, readback: bool = True, device_frames=None):
+        """Reference :1014-1039 for already selected key frames, fused with setInputCloud: transform every
+        frame by its key pose {x, y, z, roll, pitch, yaw}, concatenate, voxel-filter, build the map index.
+        `device_frames=[(ptr, n), ...]` with `frames=stride_bytes` uses clouds that already live in HBM."""
+        poses = np.ascontiguousarray(poses_xyzrpy, np.float32).reshape(-1, 6)
+        if device_frames is not None:
+            st = int(frames)
+            ptrs = (C.c_void_p * len(device_frames))(*[C.c_void_p(p) for p, _ in device_frames])
+            sizes = (C.c_size_t * len(device_frames))(*[n for _, n in device_frames])
+            nf, on_dev, keep = len(device_frames), 1, None
+        else:
+            keep = [_records(f) for f in frames]
+            st = keep[0][2] if keep else 32
+            if any(k[2] != st for k in keep):
+                raise ValueError("all key-frame clouds must share one record stride")
+            ptrs = (C.c_void_p * len(keep))(*[C.c_void_p(k[0].ctypes.data) for k in keep])
+            sizes = (C.c_size_t * len(keep))(*[k[1] for k in keep])
+            nf, on_dev = len(keep), 0
+        if poses.shape[0] != nf:
+            raise ValueError("one key pose per frame")
+        total = int(sum(sizes))
+        out = np.zeros((max(total, 1), 8), np.float32) if readback else None
+        m = C.c_size_t(0)
+        self.leaf_too_small = self._check_voxel(
+            self.lib.s2m_extract_cloud(self.h, nf, ptrs, sizes, st, on_dev, _fp(poses), leaf,
+                                       out.ctypes.data if readback else None, 32, total if readback else 0, C.byref(m)),
+            "s2m_extract_cloud")
+        self.laserCloudSurfFromMapDSNum = m.value
+        return out[:m.value] if readback else None
+
+    def transformPointCloud(self, cloudIn, pose_xyzrpy) -> np.ndarray:
+        """Reference :310-329 (PointTypePose order x, y, z, roll, pitch, yaw)."""
+        a, n, st = _records(cloudIn)
+        out = np.zeros((max(n, 1), 8), np.float32)
+        p = np.ascontiguousarray(pose_xyzrpy, np.float32)
+        self._check(self.lib.s2m_transform_cloud(self.h, a.ctypes.data, n, st, _fp(p), out.ctypes.data, 32),
+                    "s2m_transform_cloud")
+        return out[:n]
 
     # -- the path ----------------------------------------------------------
     def scan2MapOptimization(self, imu: ImuInit | None = None) -> Result:

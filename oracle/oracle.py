@@ -98,6 +98,9 @@ def lib() -> C.CDLL:
         L.orc_xy2theta.restype = C.c_float
         L.orc_makeScancontext.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]
         L.orc_makeRingkeyFromScancontext.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_voxelGrid.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_float, vp, C.c_size_t, C.c_size_t,
+                                    C.POINTER(C.c_size_t)]
+        L.orc_transformPointCloud.argtypes = [vp, C.c_size_t, C.c_size_t, fp, vp, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -269,6 +272,25 @@ def make_scancontext(pts):
     lib().orc_makeScancontext(a.ctypes.data, n, st, dp)
     lib().orc_makeRingkeyFromScancontext(dp, key.ctypes.data_as(C.POINTER(C.c_double)))
     return desc, key
+
+
+def voxel_grid(pts, leaf: float):
+    """pcl::VoxelGrid<PointXYZI> restatement: ((m, 8) float32 records, leaf_too_small flag)."""
+    a, n, st = _records(pts)
+    out = np.zeros((max(n, 1), 8), np.float32)
+    m = C.c_size_t(0)
+    rc = lib().orc_voxelGrid(a.ctypes.data, n, st, leaf, out.ctypes.data, 32, n, C.byref(m))
+    assert rc >= 0
+    return out[:m.value], bool(rc == 1)
+
+
+def transform_point_cloud(pts, pose_xyzrpy):
+    """transformPointCloud (reference :310-329); pose in PointTypePose order x, y, z, roll, pitch, yaw."""
+    a, n, st = _records(pts)
+    out = np.zeros((max(n, 1), 8), np.float32)
+    p = np.ascontiguousarray(pose_xyzrpy, np.float32)
+    lib().orc_transformPointCloud(a.ctypes.data, n, st, _fp(p), out.ctypes.data, 32)
+    return out[:n]
 
 
 def nanoflann_knn5(map_xyz, q_xyz, leaf_max: int = 15):

@@ -897,3 +897,128 @@ void orc_makeRingkeyFromScancontext(const double desc[20 * 60], double key[20])
         key[r] = s / 60.0;
     }
 }
+
+/* ==== section 8(f) rows F1 / F2: the voxel-grid filters either side of the path ================
+ * downsampleCurrentScan (:1061-1067, leaf mappingSurfLeafSize) and the VoxelGrid at the end of
+ * extractCloud (:1037-1039, leaf surroundingKeyframeMapLeafSize) both run
+ * pcl::VoxelGrid<pcl::PointXYZI>::applyFilter with default settings (downsample_all_data_ = true,
+ * min_points_per_voxel_ = 0, no filter field). PCL is not vendored: restated from PCL 1.10
+ * (filters/include/pcl/filters/impl/voxel_grid.hpp, common/include/pcl/common/impl/centroid.hpp) [ext].
+ *
+ * One thing PCL leaves to the standard library is restated as a definition: std::sort of the
+ * (voxel idx, point index) pairs compares idx only and is not stable, so the order in which the
+ * points of one voxel are summed is unspecified there; here it is ascending point index. The
+ * centroid is therefore reproducible, and differs from any one PCL build by fp32 summation order only.
+ * Points with a non-finite coordinate are skipped (PCL does so when !is_dense).
+ */
+typedef struct { uint32_t idx; uint32_t pt; } vox_pair;
+static int vox_pair_cmp(const void* a, const void* b)
+{
+    const vox_pair* x = (const vox_pair*)a; const vox_pair* y = (const vox_pair*)b;
+    if (x->idx != y->idx) return x->idx < y->idx ? -1 : 1;
+    return x->pt < y->pt ? -1 : (x->pt > y->pt ? 1 : 0);
+}
+
+int orc_voxelGrid(const void* pts, size_t n, size_t stride_bytes, float leaf,
+                  void* out, size_t out_stride_bytes, size_t cap, size_t* n_out)
+{
+    const unsigned char* b = (const unsigned char*)pts;
+    unsigned char* ob = (unsigned char*)out;
+    *n_out = 0;
+    /* getMinMax3D over the finite points */
+    float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+    size_t n_valid = 0;
+    for (size_t i = 0; i < n; i++) {
+        float p[3]; memcpy(p, b + i * stride_bytes, 12);
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+        for (int d = 0; d < 3; d++) { if (p[d] < mn[d]) mn[d] = p[d]; if (p[d] > mx[d]) mx[d] = p[d]; }
+        n_valid++;
+    }
+    if (n_valid == 0) return 0;
+    const float inv = 1.0f / leaf;                                     /* inverse_leaf_size_ = Ones / leaf_size_ */
+    /* "Leaf size is too small for the input dataset": output = input */
+    int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1,
+            dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    /* PCL multiplies in int64 (undefined past 2^63); the product is taken in double here, equal wherever PCL's is defined */
+    if ((double)dx * (double)dy * (double)dz > (double)INT32_MAX) {
+        if (n > cap) { *n_out = n; return -1; }
+        for (size_t i = 0; i < n; i++) {
+            memset(ob + i * out_stride_bytes, 0, out_stride_bytes);
+            memcpy(ob + i * out_stride_bytes, b + i * stride_bytes,
+                   stride_bytes < out_stride_bytes ? stride_bytes : out_stride_bytes);
+        }
+        *n_out = n;
+        return 1;
+    }
+    int min_b[3], max_b[3], div_b[3];
+    for (int d = 0; d < 3; d++) {
+        min_b[d] = (int)floorf(mn[d] * inv);
+        max_b[d] = (int)floorf(mx[d] * inv);
+        div_b[d] = max_b[d] - min_b[d] + 1;
+    }
+    const int mul1 = div_b[0], mul2 = div_b[0] * div_b[1];             /* divb_mul_ = (1, div0, div0*div1) */
+    vox_pair* iv = (vox_pair*)malloc(sizeof(vox_pair) * n_valid);
+    size_t k = 0;
+    for (size_t i = 0; i < n; i++) {
+        float p[3]; memcpy(p, b + i * stride_bytes, 12);
+        if (!isfinite(p[0]) || !isfinite(p[1]) || !isfinite(p[2])) continue;
+        int ijk0 = (int)(floorf(p[0] * inv) - (float)min_b[0]);
+        int ijk1 = (int)(floorf(p[1] * inv) - (float)min_b[1]);
+        int ijk2 = (int)(floorf(p[2] * inv) - (float)min_b[2]);
+        iv[k].idx = (uint32_t)(ijk0 + ijk1 * mul1 + ijk2 * mul2);
+        iv[k].pt = (uint32_t)i;
+        k++;
+    }
+    qsort(iv, n_valid, sizeof(vox_pair), vox_pair_cmp);
+    size_t total = 0, first = 0;
+    int rc = 0;
+    while (first < n_valid) {
+        size_t last = first + 1;
+        while (last < n_valid && iv[last].idx == iv[first].idx) last++;
+        if (total < cap) {
+            /* CentroidPoint<PointXYZI>: AccumulatorXYZ (Vector3f sum), AccumulatorIntensity (float sum); get() = sum / n */
+            float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+            for (size_t j = first; j < last; j++) {
+                const unsigned char* r = b + (size_t)iv[j].pt * stride_bytes;
+                float p[3]; memcpy(p, r, 12);
+                float in = 0.0f; if (stride_bytes >= 20) memcpy(&in, r + 16, 4);
+                sx += p[0]; sy += p[1]; sz += p[2]; si += in;
+            }
+            const float cnt = (float)(last - first);
+            float rec[5] = { sx / cnt, sy / cnt, sz / cnt, 1.0f, si / cnt };
+            unsigned char* o = ob + total * out_stride_bytes;
+            memset(o, 0, out_stride_bytes);
+            memcpy(o, rec, out_stride_bytes >= 20 ? 20 : (out_stride_bytes >= 16 ? 16 : 12));
+        } else rc = -1;
+        total++;
+        first = last;
+    }
+    free(iv);
+    *n_out = total;
+    return rc;
+}
+
+/* transformPointCloud (:310-329): T = pcl::getTransformation(x, y, z, roll, pitch, yaw) of a
+ * PointTypePose, applied as written (fp32, three products and three adds per row); intensity copied. */
+void orc_transformPointCloud(const void* pts, size_t n, size_t stride_bytes, const float pose_xyzrpy[6],
+                             void* out, size_t out_stride_bytes)
+{
+    float t[6] = { pose_xyzrpy[3], pose_xyzrpy[4], pose_xyzrpy[5], pose_xyzrpy[0], pose_xyzrpy[1], pose_xyzrpy[2] };
+    float T[12];
+    orc_getTransformation(t, T);
+    const unsigned char* b = (const unsigned char*)pts;
+    unsigned char* ob = (unsigned char*)out;
+    for (size_t i = 0; i < n; i++) {
+        const unsigned char* r = b + i * stride_bytes;
+        float p[3]; memcpy(p, r, 12);
+        float in = 0.0f; if (stride_bytes >= 20) memcpy(&in, r + 16, 4);
+        float rec[5];
+        rec[0] = T[0] * p[0] + T[1] * p[1] + T[2] * p[2] + T[3];
+        rec[1] = T[4] * p[0] + T[5] * p[1] + T[6] * p[2] + T[7];
+        rec[2] = T[8] * p[0] + T[9] * p[1] + T[10] * p[2] + T[11];
+        rec[3] = 1.0f; rec[4] = in;
+        unsigned char* o = ob + i * out_stride_bytes;
+        memset(o, 0, out_stride_bytes);
+        memcpy(o, rec, out_stride_bytes >= 20 ? 20 : (out_stride_bytes >= 16 ? 16 : 12));
+    }
+}

@@ -114,6 +114,14 @@ float    orc_xy2theta(float x, float y);
 void     orc_makeScancontext(const void* pts, size_t n, size_t stride_bytes, double desc[20 * 60]);
 void     orc_makeRingkeyFromScancontext(const double desc[20 * 60], double key[20]);
 
+/* section 8(f) rows F1/F2: pcl::VoxelGrid<PointXYZI>::applyFilter [ext] (:1037-1039, :1061-1067) and
+ * transformPointCloud (:310-329). orc_voxelGrid returns 0 ok, 1 "leaf size too small" (output = input),
+ * -1 output capacity too small (*n_out = needed). pose_xyzrpy = PointTypePose {x, y, z, roll, pitch, yaw}. */
+int      orc_voxelGrid(const void* pts, size_t n, size_t stride_bytes, float leaf,
+                       void* out, size_t out_stride_bytes, size_t cap, size_t* n_out);
+void     orc_transformPointCloud(const void* pts, size_t n, size_t stride_bytes, const float pose_xyzrpy[6],
+                                 void* out, size_t out_stride_bytes);
+
 #ifdef __cplusplus
 }
 #endif
