@@ -8,6 +8,7 @@
 // call scan2MapOptimization(), read transformTobeMapped / isDegenerate /
 // incrementalOdometryAffineBack.  All arithmetic runs in the HIP library; there is no CPU path here.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -26,6 +27,13 @@ struct alignas(16) PointXYZI {
 };
 static_assert(sizeof(PointXYZI) == 32, "PointXYZI must match pcl::PointXYZI");
 
+// PointTypePose (reference include/utility.h:66-83): key pose with the id in `intensity`.
+struct PointTypePose {
+    float x = 0, y = 0, z = 0, intensity = 0;
+    float roll = 0, pitch = 0, yaw = 0;
+    double time = 0;
+};
+
 // The fields of liorf::cloud_info this path reads (reference msg/cloud_info.msg:10-16).
 struct CloudInfo {
     int64_t imuAvailable = 0;
@@ -41,6 +49,13 @@ public:
     std::vector<PointXYZI> laserCloudSurfFromMapDS;   // local surf map, voxel-filtered (:124)
     std::vector<PointXYZI> laserCloudSurfLastDS;      // current scan, voxel-filtered (:108)
     int   laserCloudSurfLastDSNum = 0;                // (:131)
+    int   laserCloudSurfFromMapDSNum = 0;             // (:130)
+    std::vector<PointXYZI> laserCloudSurfLast;        // current scan before the filter (:107)
+    std::vector<std::vector<PointXYZI>> surfCloudKeyFrames;   // key-frame clouds (:93)
+    std::vector<PointTypePose> cloudKeyPoses6D;       // (:96)
+    float mappingSurfLeafSize = 0.2f;                 // include/utility.h:227 (the shipped yaml files set 0.4)
+    float surroundingKeyframeMapLeafSize = 0.2f;      // include/utility.h:228
+    float surroundingKeyframeSearchRadius = 50.0f;    // include/utility.h:240
     float transformTobeMapped[6] = { 0, 0, 0, 0, 0, 0 };   // roll,pitch,yaw,x,y,z (:134)
     bool  isDegenerate = false;                       // (:139)
     float incrementalOdometryAffineBack[12] = { 0 };  // row-major 3x4 (:157)
@@ -76,15 +91,68 @@ public:
                           sizeof(PointXYZI)), "s2m_set_map");
     }
 
+    // void downsampleCurrentScan() (:1061-1067): laserCloudSurfLast -> laserCloudSurfLastDS on the device;
+    // the filtered scan stays resident for scan2MapOptimization() and is copied back for the key-frame store
+    void downsampleCurrentScan()
+    {
+        laserCloudSurfLastDS.resize(laserCloudSurfLast.size());
+        size_t n_out = 0;
+        checkVoxel(s2m_downsample_scan(h_, laserCloudSurfLast.data(), laserCloudSurfLast.size(), sizeof(PointXYZI), 0,
+                                       mappingSurfLeafSize, laserCloudSurfLastDS.data(), sizeof(PointXYZI),
+                                       laserCloudSurfLastDS.size(), &n_out), "s2m_downsample_scan");
+        laserCloudSurfLastDS.resize(n_out);
+        laserCloudSurfLastDSNum = (int)n_out;
+        scanResident_ = true;
+    }
+
+    // void extractCloud(cloudToExtract) (:1014-1039): `keyInds` are the key-frame ids the caller's radius
+    // search and time filter chose (extractNearby, :973-1012). Frames farther than
+    // surroundingKeyframeSearchRadius from the newest key pose are dropped (:1018), the rest are transformed
+    // by their key pose, concatenated, voxel-filtered and indexed on the device; there is no
+    // laserCloudMapContainer cache to maintain.
+    void extractCloud(const std::vector<int>& keyInds)
+    {
+        std::vector<const void*> frames;
+        std::vector<size_t> sizes;
+        std::vector<float> poses;
+        size_t total = 0;
+        if (!cloudKeyPoses6D.empty()) {
+            const PointTypePose& last = cloudKeyPoses6D.back();
+            for (int k : keyInds) {
+                const PointTypePose& p = cloudKeyPoses6D[(size_t)k];
+                const float dx = p.x - last.x, dy = p.y - last.y, dz = p.z - last.z;
+                if (std::sqrt(dx * dx + dy * dy + dz * dz) > surroundingKeyframeSearchRadius) continue;
+                frames.push_back(surfCloudKeyFrames[(size_t)k].data());
+                sizes.push_back(surfCloudKeyFrames[(size_t)k].size());
+                const float v[6] = { p.x, p.y, p.z, p.roll, p.pitch, p.yaw };
+                poses.insert(poses.end(), v, v + 6);
+                total += sizes.back();
+            }
+        }
+        laserCloudSurfFromMapDS.resize(total);
+        size_t n_out = 0;
+        checkVoxel(s2m_extract_cloud(h_, (int)frames.size(), frames.data(), sizes.data(), sizeof(PointXYZI), 0, poses.data(),
+                                     surroundingKeyframeMapLeafSize, laserCloudSurfFromMapDS.data(), sizeof(PointXYZI),
+                                     total, &n_out), "s2m_extract_cloud");
+        laserCloudSurfFromMapDS.resize(n_out);
+        laserCloudSurfFromMapDSNum = (int)n_out;
+        haveKeyPoses = !cloudKeyPoses6D.empty();
+    }
+
     // void scan2MapOptimization() (:1295-1321)
     void scan2MapOptimization()
     {
-        laserCloudSurfLastDSNum = (int)laserCloudSurfLastDS.size();
         s2m_imu_init imu;
         imu.imuAvailable = cloudInfo.imuAvailable;
         imu.imuRollInit = cloudInfo.imuRollInit; imu.imuPitchInit = cloudInfo.imuPitchInit; imu.imuYawInit = cloudInfo.imuYawInit;
-        check(s2m_optimize(h_, laserCloudSurfLastDS.data(), laserCloudSurfLastDS.size(), sizeof(PointXYZI),
-                           transformTobeMapped, &imu, &lastResult), "s2m_optimize");
+        if (scanResident_) {        // downsampleCurrentScan() left the scan on the device
+            scanResident_ = false;
+            check(s2m_optimize_resident(h_, transformTobeMapped, &imu, &lastResult), "s2m_optimize_resident");
+        } else {
+            laserCloudSurfLastDSNum = (int)laserCloudSurfLastDS.size();
+            check(s2m_optimize(h_, laserCloudSurfLastDS.data(), laserCloudSurfLastDS.size(), sizeof(PointXYZI),
+                               transformTobeMapped, &imu, &lastResult), "s2m_optimize");
+        }
         if (lastResult.skipped == 2) {
             // ROS_WARN("Not enough features! Only %d planar features available.", ...) (:1319)
             return;
@@ -102,7 +170,10 @@ private:
     {
         if (rc != S2M_OK) throw std::runtime_error(std::string(what) + ": " + s2m_last_error(h_));
     }
+    // S2M_WARN_LEAF_TOO_SMALL is PCL's PCL_WARN case (output = input): not an error
+    void checkVoxel(int rc, const char* what) { if (rc != S2M_WARN_LEAF_TOO_SMALL) check(rc, what); }
     s2m_handle h_ = nullptr;
+    bool scanResident_ = false;
 };
 
 }  // namespace liorf_amd

@@ -3,6 +3,10 @@
 // scan2MapOptimization() through the host mirror, prints the result.  Fails loudly without a GPU.
 //
 //   s2m_harness map.bin scan.bin roll pitch yaw x y z
+//   s2m_harness --chain frames.bin frames.txt raw_scan.bin map_leaf scan_leaf roll pitch yaw x y z
+//       the handler's three steps in order: extractCloud() over the key frames listed in frames.txt (one line
+//       "n_points x y z roll pitch yaw" per frame, clouds back to back in frames.bin), downsampleCurrentScan(),
+//       scan2MapOptimization().
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -21,10 +25,48 @@ static std::vector<liorf_amd::PointXYZI> read_cloud(const char* path)
     return pts;
 }
 
+static void print_result(const liorf_amd::MapOptimizationS2M& node)
+{
+    const s2m_result& r = node.lastResult;
+    std::printf("skipped %d iters %d converged %d degenerate %d n_sel %d\n", r.skipped, r.iters_run, r.converged, r.is_degenerate, r.n_sel_last);
+    std::printf("transformTobeMapped %.9g %.9g %.9g %.9g %.9g %.9g\n", node.transformTobeMapped[0], node.transformTobeMapped[1],
+                node.transformTobeMapped[2], node.transformTobeMapped[3], node.transformTobeMapped[4], node.transformTobeMapped[5]);
+}
+
+static int run_chain(char** argv)
+{
+    liorf_amd::MapOptimizationS2M node;
+    const std::vector<liorf_amd::PointXYZI> all = read_cloud(argv[2]);
+    std::ifstream tab(argv[3]);
+    if (!tab) throw std::runtime_error(std::string("cannot open ") + argv[3]);
+    size_t n, at = 0;
+    liorf_amd::PointTypePose p;
+    std::vector<int> keyInds;
+    while (tab >> n >> p.x >> p.y >> p.z >> p.roll >> p.pitch >> p.yaw) {
+        if (at + n > all.size()) throw std::runtime_error("frames.txt asks for more points than frames.bin holds");
+        p.intensity = (float)node.cloudKeyPoses6D.size();
+        keyInds.push_back((int)node.cloudKeyPoses6D.size());
+        node.cloudKeyPoses6D.push_back(p);
+        node.surfCloudKeyFrames.emplace_back(all.begin() + (std::ptrdiff_t)at, all.begin() + (std::ptrdiff_t)(at + n));
+        at += n;
+    }
+    node.laserCloudSurfLast = read_cloud(argv[4]);
+    node.surroundingKeyframeMapLeafSize = (float)std::atof(argv[5]);
+    node.mappingSurfLeafSize = (float)std::atof(argv[6]);
+    for (int k = 0; k < 6; k++) node.transformTobeMapped[k] = (float)std::atof(argv[7 + k]);
+    node.extractCloud(keyInds);
+    node.downsampleCurrentScan();
+    node.scan2MapOptimization();
+    std::printf("laserCloudSurfFromMapDSNum %d laserCloudSurfLastDSNum %d\n", node.laserCloudSurfFromMapDSNum, node.laserCloudSurfLastDSNum);
+    print_result(node);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     try {
         if (argc == 2 && std::string(argv[1]) == "--version") { std::puts(s2m_version()); return 0; }
+        if (argc == 13 && std::string(argv[1]) == "--chain") return run_chain(argv);
         if (argc != 9) { std::fprintf(stderr, "usage: %s map.bin scan.bin roll pitch yaw x y z\n", argv[0]); return 2; }
         liorf_amd::MapOptimizationS2M node;                 // throws without a gfx950 device
         node.laserCloudSurfFromMapDS = read_cloud(argv[1]);
@@ -33,10 +75,7 @@ int main(int argc, char** argv)
         for (int k = 0; k < 6; k++) node.transformTobeMapped[k] = (float)std::atof(argv[3 + k]);
         node.setInputCloud();
         node.scan2MapOptimization();
-        const s2m_result& r = node.lastResult;
-        std::printf("skipped %d iters %d converged %d degenerate %d n_sel %d\n", r.skipped, r.iters_run, r.converged, r.is_degenerate, r.n_sel_last);
-        std::printf("transformTobeMapped %.9g %.9g %.9g %.9g %.9g %.9g\n", node.transformTobeMapped[0], node.transformTobeMapped[1],
-                    node.transformTobeMapped[2], node.transformTobeMapped[3], node.transformTobeMapped[4], node.transformTobeMapped[5]);
+        print_result(node);
         return 0;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "s2m_harness: %s\n", e.what());

@@ -155,3 +155,36 @@ def test_extract_cloud_ragged_frames(gpu):
     frames[2] = frames[2][:1]
     _same_records(gpu.extractCloud(frames, poses, 0.5), _oracle_extract(frames, poses, 0.5))
     assert gpu.extractCloud([], np.zeros((0, 6), np.float32), 0.5).shape[0] == 0
+
+
+def test_cpp_host_mirror_chain(gpu, tmp_path):
+    """The C++ mirror's extractCloud() -> downsampleCurrentScan() -> scan2MapOptimization() (the order of
+    laserCloudInfoHandler, reference :257-265) against the oracle's chain."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "liorf_amd", "host")])
+    exe = os.path.join(root, "liorf_amd", "host", "s2m_harness")
+    scene, frames, poses = _key_frames(n_frames=5, n_pts=6000)
+    pose_gt = np.array([0.012, -0.01, 0.4, 1.0, 0.9, 0.0])
+    raw = synth.to_xyzi(synth.make_scan(scene, pose_gt, "velodyne64", 15000, seed=78))
+    (tmp_path / "frames.bin").write_bytes(np.concatenate(frames, 0).tobytes())
+    (tmp_path / "frames.txt").write_text("".join(
+        "%d %s\n" % (f.shape[0], " ".join("%.9g" % v for v in p)) for f, p in zip(frames, poses)))
+    (tmp_path / "raw.bin").write_bytes(raw.tobytes())
+    pose0 = np.array([float("%.9g" % v) for v in synth.pose_init_from(pose_gt)], np.float32)
+    out = subprocess.run([exe, "--chain", str(tmp_path / "frames.bin"), str(tmp_path / "frames.txt"), str(tmp_path / "raw.bin"),
+                          "0.5", "0.4"] + ["%.9g" % v for v in pose0], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    poses_rt = np.array([[float("%.9g" % v) for v in p] for p in poses], np.float32)
+    ref_map = _oracle_extract(frames, poses_rt, 0.5)
+    ref_scan, _ = O.voxel_grid(raw, 0.4)
+    assert lines[0] == "laserCloudSurfFromMapDSNum %d laserCloudSurfLastDSNum %d" % (ref_map.shape[0], ref_scan.shape[0])
+    orc = O.Oracle(knn_backend=1, num_threads=8)
+    orc.set_map(ref_map)
+    orc.set_scan(ref_scan)
+    ro = orc.scan2MapOptimization(pose0)
+    assert ("iters %d " % ro.iters_run) in lines[1]
+    got = np.array([float(v) for v in lines[2].split()[1:]], np.float32)
+    assert np.abs(got - np.array(ro.pose)).max() <= 1e-4

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Times the voxel-grid stages that feed the path on device-resident
+clouds, next to the CPU oracle on the same inputs.  Not the headline metric (bench.py is); prints one JSON line.
+
+  python tools/bench_voxel.py [--frames 50] [--frame-pts 30000] [--raw-pts 120000]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=50)
+    ap.add_argument("--frame-pts", type=int, default=30000)
+    ap.add_argument("--raw-pts", type=int, default=120000)
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from liorf_amd import s2m, synth
+    scene = synth.make_scene(seed=11, half=70.0, n_boxes=92)
+    rng = np.random.default_rng(1)
+    frames, poses = [], []
+    base = None
+    for k in range(args.frames):
+        pose_gt = np.array([0.01 * np.sin(k), -0.008 * np.cos(k), 0.05 * k, 1.2 * k - 0.6 * args.frames, 0.3 * np.sin(0.3 * k), 0.0])
+        if k < 4 or base is None:         # ray casting is slow on the CPU: a few distinct sweeps, reused
+            base = synth.to_xyzi(synth.make_scan(scene, pose_gt, "velodyne64", args.frame_pts, seed=100 + k))
+            base[:, 4] = rng.uniform(0, 100, args.frame_pts).astype(np.float32)
+        frames.append(base)
+        poses.append(np.r_[pose_gt[3:], pose_gt[:3]].astype(np.float32))
+    poses = np.stack(poses)
+    raw = synth.to_xyzi(synth.make_scan(scene, np.array([0, 0, 0.1, 0.5, 0.2, 0.0]), "velodyne64", args.raw_pts, seed=7))
+
+    eng = s2m.MapOptimizationS2M()
+    d_frames = [torch.from_numpy(f).cuda() for f in frames]
+    d_raw = torch.from_numpy(raw).cuda()
+    torch.cuda.synchronize()
+    dev = [(t.data_ptr(), t.shape[0]) for t in d_frames]
+
+    def timed(fn):
+        fn(); fn()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            fn()
+        return (time.perf_counter() - t0) / args.reps * 1e3
+
+    ms_extract = timed(lambda: eng.extractCloud(32, poses, 0.5, readback=False, device_frames=dev))
+    n_map = eng.laserCloudSurfFromMapDSNum
+    ms_scan = timed(lambda: eng.downsampleCurrentScan(None, 0.4, readback=False, device_ptr=(d_raw.data_ptr(), raw.shape[0], 32)))
+    n_scan = eng.laserCloudSurfLastDSNum
+    out = {"extractCloud_ms": round(ms_extract, 3), "frames": args.frames, "points_in": int(sum(n for _, n in dev)),
+           "laserCloudSurfFromMapDSNum": n_map, "downsampleCurrentScan_ms": round(ms_scan, 3), "raw_scan_points": raw.shape[0],
+           "laserCloudSurfLastDSNum": n_scan,
+           "note": "wall clock per call incl. map index build / scan prep and the final synchronisation; inputs resident in HBM"}
+    if not args.no_cpu:
+        from oracle import oracle as O
+        t0 = time.perf_counter()
+        cat = np.concatenate([O.transform_point_cloud(f, p) for f, p in zip(frames, poses)], 0)
+        ref_map, _ = O.voxel_grid(cat, 0.5)
+        t1 = time.perf_counter()
+        ref_scan, _ = O.voxel_grid(raw, 0.4)
+        t2 = time.perf_counter()
+        out["cpu_port"] = {"extractCloud_ms": round((t1 - t0) * 1e3, 2), "downsampleCurrentScan_ms": round((t2 - t1) * 1e3, 2), "cores": 1}
+        out["parity"] = {"map_voxels_equal": bool(ref_map.shape[0] == n_map), "scan_voxels_equal": bool(ref_scan.shape[0] == n_scan)}
+    print(json.dumps(out))
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()
