@@ -252,7 +252,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     if (nblocks == 0) nblocks = kBlocksQuantum;
     h->hctx.nblocks = nblocks;
     h->ctx_dirty = true;
-    if ((rc = ensure(h, h->partials, sizeof(double) * kAcc * (size_t)nblocks))) return rc;
+    if ((rc = ensure(h, h->partials, sizeof(double) * 2 * kAcc * (size_t)nblocks))) return rc;   // two slots, by launch parity
     h->hctx.partials = h->partials.as<double>();
     if (n == 0) { h->t_set_scan_ms = 0; h->scan_timing_pending = false; return upload_ctx(h); }
 
@@ -320,6 +320,7 @@ void fill_state(s2m_context* h, DevState* s, const float pose[6])
 {
     memset(s, 0, sizeof(*s));
     memcpy(s->pose, pose, 24);
+    memcpy(s->pose2[0], pose, 24);       // launch 0 runs with slot 0
     host_pose_to_transform(pose, s->T, s->sc);
     s->T_valid = 1;
     memcpy(s->matP, h->persist_matP, sizeof(s->matP));
@@ -335,6 +336,22 @@ int push_state(s2m_context* h, const float pose[6])
     return S2M_OK;
 }
 
+// The LM loop (:1304-1315) as a launch sequence.  k_register(L) does the per-point work of iteration L;
+// iteration 0 is closed by k_finalize (it carries the degeneracy analysis), iterations 1..n-2 are
+// closed inside the prologue of the following k_register (solve_prev), the last one by k_finalize:
+//   R0 F0 R1 R2' R3' ... R(n-1)' F(n-1)        (' = closes the iteration before it)
+// `events`, if given, holds 2*n events recorded around every k_register launch.
+void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* events)
+{
+    const int n = h->prm.max_iter;
+    for (int L = 0; L < n; L++) {
+        if (events) (void)hipEventRecord(events[2 * L], h->stream);
+        hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, L, (L >= 2) ? 1 : 0);
+        if (events) (void)hipEventRecord(events[2 * L + 1], h->stream);
+        if (L == 0 || L == n - 1) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, L, 0);
+    }
+}
+
 int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
 {
     auto it = h->graphs.find(nblocks);
@@ -343,10 +360,7 @@ int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
     hipGraphExec_t exec = nullptr;
     const DevCtx* dc = h->dctx.as<DevCtx>();
     S2M_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    for (int it2 = 0; it2 < h->prm.max_iter; it2++) {
-        hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, it2, 0);
-    }
+    enqueue_loop(h, nblocks, dc, nullptr);
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "hipStreamEndCapture", e);
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -373,10 +387,7 @@ int launch_loop(s2m_context* h)
     }
     const DevCtx* dc = h->dctx.as<DevCtx>();
     S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
-    for (int it = 0; it < h->prm.max_iter; it++) {
-        hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, it, 0);
-    }
+    enqueue_loop(h, nblocks, dc, nullptr);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
     return S2M_OK;
@@ -471,7 +482,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (hipHostMalloc((void**)&h->h_sc, sizeof(double) * 1220) != hipSuccess) return bail(S2M_ERR_HIP);
     if (ensure(h, h->state, sizeof(DevState)) || ensure(h, h->trace, sizeof(s2m_iter_trace) * kMaxIter) ||
         ensure(h, h->dctx, sizeof(DevCtx)) || ensure(h, h->mm, 64) ||
-        ensure(h, h->partials, sizeof(double) * kAcc * kBlocksQuantum) ||
+        ensure(h, h->partials, sizeof(double) * 2 * kAcc * kBlocksQuantum) ||
         ensure(h, h->sc_bins, sizeof(uint32_t) * 1200) || ensure(h, h->sc_out, sizeof(double) * 1220))
         return bail(S2M_ERR_HIP);
 
@@ -637,7 +648,7 @@ int s2m_surf_optimization(s2m_handle h, const float pose[6], int32_t* idx5, floa
     h->ctx_dirty = true;
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
-    hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>());
+    hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), 0, 0);
     S2M_HIP(h, hipGetLastError());
     if (idx5) S2M_HIP(h, hipMemcpyAsync(idx5, h->dbg_idx5.p, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, h->stream));
     if (d2_5) S2M_HIP(h, hipMemcpyAsync(d2_5, h->dbg_d2.p, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, h->stream));
@@ -663,7 +674,7 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
     for (int rep = 0; rep < launches; rep++)
-        hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>());
+        hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), 0, 0);
     S2M_HIP(h, hipGetLastError());
     const size_t n = nwaves < cap_waves ? nwaves : cap_waves;
     S2M_HIP(h, hipMemcpyAsync(out, h->dbg_clk.p, sizeof(uint64_t) * 16 * n, hipMemcpyDeviceToHost, h->stream));
@@ -689,7 +700,7 @@ int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6]
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
     const DevCtx* dc = h->dctx.as<DevCtx>();
-    hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
+    hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, 0, 0);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, 0, 1);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
@@ -736,16 +747,10 @@ int s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float
         S2M_HIP(h, hipMemsetAsync(h->prior_valid.p, 0, sizeof(int32_t) * h->n_q, h->stream));
         S2M_HIP(h, hipMemsetAsync(h->plane_state.p, 0, sizeof(int32_t) * h->n_q, h->stream));
         if ((rc = push_state(h, pose))) return rc;
-        for (int it = 0; it < nit; it++) {          // the real loop, launched one by one between event pairs
-            S2M_HIP(h, hipEventRecord(h->iter_events[2 * it], h->stream));
-            hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc);
-            S2M_HIP(h, hipEventRecord(h->iter_events[2 * it + 1], h->stream));
-            hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, it, 0);
-        }
+        enqueue_loop(h, h->hctx.nblocks, dc, h->iter_events.data());     // the real loop, launched one by one between event pairs
         S2M_HIP(h, hipGetLastError());
         S2M_HIP(h, hipStreamSynchronize(h->stream));
-        const int ran = std::min(nit, std::max(1, (int)0x7fffffff));
-        for (int it = 0; it < ran; it++) {
+        for (int it = 0; it < nit; it++) {
             float ms = 0;
             S2M_HIP(h, hipEventElapsedTime(&ms, h->iter_events[2 * it], h->iter_events[2 * it + 1]));
             total_ms += ms; launches++;

@@ -655,8 +655,397 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v)
 __device__ __forceinline__ constexpr int run_dy(int k) { return (int)((139617u >> (2 * k)) & 3u) - 1; }
 __device__ __forceinline__ constexpr int run_dz(int k) { return (int)((164373u >> (2 * k)) & 3u) - 1; }
 
+// ------------------------------------------------------------------------------------------
+// 6x6 algebra of LMOptimization (:1237-1271)
+// ------------------------------------------------------------------------------------------
+// cv::eigen (:1248): max-pivot Jacobi in fp32, eigenvalues descending, eigenvectors as rows.
+// A and V are LDS scratch of the calling lane (data-dependent indexing).
+__device__ void eigen6_sym(float (*A)[6], float (*V)[6], float* W, int* indR, int* indC)
+{
+    constexpr int N = 6;
+    const float eps = FLT_EPSILON;
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) V[i][j] = (i == j) ? 1.0f : 0.0f;
+    for (int k = 0; k < N; k++) {
+        W[k] = A[k][k];
+        if (k < N - 1) {
+            int m = k + 1; float mv = fabsf(A[k][m]);
+            for (int i = k + 2; i < N; i++) { float v = fabsf(A[k][i]); if (mv < v) { mv = v; m = i; } }
+            indR[k] = m;
+        }
+        if (k > 0) {
+            int m = 0; float mv = fabsf(A[0][k]);
+            for (int i = 1; i < k; i++) { float v = fabsf(A[i][k]); if (mv < v) { mv = v; m = i; } }
+            indC[k] = m;
+        }
+    }
+    for (int it = 0; it < N * N * 30; it++) {
+        int k = 0, l; float mv = fabsf(A[0][indR[0]]);
+        for (int i = 1; i < N - 1; i++) { float v = fabsf(A[i][indR[i]]); if (mv < v) { mv = v; k = i; } }
+        l = indR[k];
+        for (int i = 1; i < N; i++) { float v = fabsf(A[indC[i]][i]); if (mv < v) { mv = v; k = indC[i]; l = i; } }
+        const float p = A[k][l];
+        if (fabsf(p) <= eps) break;
+        const float y = (W[l] - W[k]) * 0.5f;
+        float t = fabsf(y) + hypotf(p, y);
+        float s = hypotf(p, t);
+        const float c = t / s;
+        s = p / s; t = (p / t) * p;
+        if (y < 0.0f) { s = -s; t = -t; }
+        A[k][l] = 0.0f;
+        W[k] -= t; W[l] += t;
+#define S2M_ROT(v0, v1) do { const float a0 = (v0), b0 = (v1); (v0) = a0 * c - b0 * s; (v1) = a0 * s + b0 * c; } while (0)
+        for (int i = 0; i < k; i++)     S2M_ROT(A[i][k], A[i][l]);
+        for (int i = k + 1; i < l; i++) S2M_ROT(A[k][i], A[i][l]);
+        for (int i = l + 1; i < N; i++) S2M_ROT(A[k][i], A[l][i]);
+        for (int i = 0; i < N; i++)     S2M_ROT(V[k][i], V[l][i]);
+#undef S2M_ROT
+        for (int j = 0; j < 2; j++) {
+            const int idx = j == 0 ? k : l;
+            if (idx < N - 1) {
+                int m = idx + 1; float mv2 = fabsf(A[idx][m]);
+                for (int i = idx + 2; i < N; i++) { float v = fabsf(A[idx][i]); if (mv2 < v) { mv2 = v; m = i; } }
+                indR[idx] = m;
+            }
+            if (idx > 0) {
+                int m = 0; float mv2 = fabsf(A[0][idx]);
+                for (int i = 1; i < idx; i++) { float v = fabsf(A[i][idx]); if (mv2 < v) { mv2 = v; m = i; } }
+                indC[idx] = m;
+            }
+        }
+    }
+    for (int k = 0; k < N - 1; k++) {
+        int m = k;
+        for (int i = k + 1; i < N; i++) if (W[m] < W[i]) m = i;
+        if (k != m) {
+            float tw = W[m]; W[m] = W[k]; W[k] = tw;
+            for (int i = 0; i < N; i++) { float tv = V[m][i]; V[m][i] = V[k][i]; V[k][i] = tv; }
+        }
+    }
+}
+
+// cv::Mat::inv() (:1263): LU with partial pivoting applied to [A | I], fp32. A is destroyed.
+__device__ bool inv6_lu(float (*A)[6], float (*B)[6])
+{
+    constexpr int N = 6;
+    const float eps = FLT_EPSILON * 10.0f;
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) B[i][j] = (i == j) ? 1.0f : 0.0f;
+    for (int i = 0; i < N; i++) {
+        int k = i;
+        for (int j = i + 1; j < N; j++) if (fabsf(A[j][i]) > fabsf(A[k][i])) k = j;
+        if (fabsf(A[k][i]) < eps) {
+            for (int a = 0; a < N; a++) for (int b = 0; b < N; b++) B[a][b] = 0.0f;
+            return false;
+        }
+        if (k != i) {
+            for (int j = i; j < N; j++) { float t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t; }
+            for (int j = 0; j < N; j++) { float t = B[i][j]; B[i][j] = B[k][j]; B[k][j] = t; }
+        }
+        const float d = -1.0f / A[i][i];
+        for (int j = i + 1; j < N; j++) {
+            const float alpha = A[j][i] * d;
+            for (int m = i + 1; m < N; m++) A[j][m] += alpha * A[i][m];
+            for (int m = 0; m < N; m++) B[j][m] += alpha * B[i][m];
+        }
+    }
+    for (int i = N - 1; i >= 0; i--)
+        for (int j = 0; j < N; j++) {
+            float s = B[i][j];
+            for (int k = i + 1; k < N; k++) s -= A[i][k] * B[k][j];
+            B[i][j] = s / A[i][i];
+        }
+    return true;
+}
+
+__device__ __forceinline__ void store_trace(gptr<s2m_iter_trace> dst, const s2m_iter_trace& tr)
+{
+    dst->n_sel = tr.n_sel; dst->stepped = tr.stepped; dst->deltaR = tr.deltaR; dst->deltaT = tr.deltaT;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { dst->delta[k] = tr.delta[k]; dst->pose[k] = tr.pose[k]; }
+}
+
+// cv::solve(matAtA, matAtB, matX, DECOMP_QR) (:1240) spread over 7 lanes of one wave: lane j < 6
+// owns column j of AtA, lane 6 the right-hand side.  Per reflector l: lane l builds the unit vector
+// (the only serial part: two sqrt, 6-l divides), every owner updates its own column, lane 6
+// applies the stored form of the reflector to b.  Each number goes through exactly the
+// operations, in the order, of OpenCV's hal::QR32f (un-pivoted Householder QR in fp32 with unit-length
+// reflectors, rhs transformed, back substitution; OpenCV >= 3.3).  `sv` is 8 floats of LDS.
+__device__ __forceinline__ bool solve6_qr_lanes(int lane, float (&col)[6], float* sv, float (*sA)[8], float (&x)[6])
+{
+#pragma unroll
+    for (int l = 0; l < 6; l++) {
+        if (lane == l) {
+            float vl[6];
+            float nrm = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6 - l; i++) { vl[i] = col[l + i]; nrm += vl[i] * vl[i]; }
+            const float tmpV = vl[0];
+            vl[0] = vl[0] + (vl[0] >= 0.0f ? 1.0f : -1.0f) * sqrtf(nrm);
+            nrm = sqrtf(nrm + vl[0] * vl[0] - tmpV * tmpV);
+#pragma unroll
+            for (int i = 0; i < 6 - l; i++) { vl[i] /= nrm; sv[i] = vl[i]; }
+        }
+        wave_lds_sync();
+        float vl[6];
+#pragma unroll
+        for (int i = 0; i < 6 - l; i++) vl[i] = sv[i];
+        if (lane >= l && lane < 6) {
+            float v = 0.0f;
+#pragma unroll
+            for (int i = l; i < 6; i++) v += vl[i - l] * col[i];
+#pragma unroll
+            for (int i = l; i < 6; i++) col[i] -= 2.0f * vl[i - l] * v;
+            if (lane == l) {
+#pragma unroll
+                for (int i = 1; i < 6 - l; i++) col[l + i] = vl[i] / vl[0];
+            }
+        } else if (lane == 6) {
+            const float hf = vl[0] * vl[0];
+            float u[6];
+            u[0] = 1.0f;
+#pragma unroll
+            for (int i = 1; i < 6 - l; i++) u[i] = vl[i] / vl[0];
+            float v = 0.0f;
+#pragma unroll
+            for (int i = l; i < 6; i++) v += u[i - l] * col[i];
+#pragma unroll
+            for (int i = l; i < 6; i++) col[i] -= 2.0f * u[i - l] * v * hf;
+        }
+        wave_lds_sync();
+    }
+    if (lane < 7) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) sA[i][lane] = col[i];
+    }
+    wave_lds_sync();
+    bool ok = true;
+    float b[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) b[i] = sA[i][6];
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+#pragma unroll
+        for (int j = 5; j > i; j--) b[i] -= b[j] * sA[i][j];
+        if (fabsf(sA[i][i]) < FLT_EPSILON * 10.0f) ok = false;
+        b[i] /= sA[i][i];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = ok ? b[i] : 0.0f;
+    return ok;
+}
+
+// Is every eigenvalue of the symmetric 6x6 A safely above `thresh`?  Cholesky of A - s*I in
+// fp64 with s = thresh + margin, margin = 1e-5 * trace(A) (far above the fp32 Jacobi's error of a
+// few ulp of the largest eigenvalue, far below any eigenvalue that matters): if it succeeds,
+// cv::eigen would report all six eigenvalues >= thresh and isDegenerate stays false (:1251-1262).
+__device__ bool all_eigen_above(const float* A, float thresh)
+{
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) tr += (double)A[i * 6 + i];
+    if (!(tr > 0.0) || !(tr < 1.0e30)) return false;
+    const double sft = (double)thresh + 1e-5 * tr;
+    double L[6][6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = (double)A[j * 6 + j] - sft;
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
+        if (!(d > 1e-9 * tr)) return false;
+        const double dj = sqrt(d);
+        L[j][j] = dj;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = (double)A[i * 6 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+            L[i][j] = v / dj;
+        }
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// The rest of LMOptimization (:1177-1292) after the per-point work: second stage of the
+// AtA/AtB reduction (fixed order: bitwise reproducible for a given workgroup partition and
+// workgroup size), the 6x6 solve, the iteration-0 degeneracy analysis, the pose update and the
+// convergence test.  Two callers share it:
+//   * k_finalize (one workgroup of 1024) closes iteration 0, which needs the degeneracy
+//     analysis, and the last iteration of a scan;
+//   * k_register closes iteration L-1 in the prologue of launch L >= 2: every workgroup reduces
+//     the previous launch's partial sums and solves the 6x6 system for itself (same numbers in
+//     the same order, so every workgroup arrives at the same pose), and workgroup 0 records
+//     the outcome.  That removes a kernel boundary and a single-workgroup kernel from every
+//     iteration of the loop (:1304-1315); the few microseconds of redundant algebra overlap
+//     with the loads of the scan points and their priors.
+// Loop state is double-buffered by launch parity so that nothing read in a launch is written
+// in it: launch L uses the pose in pose2[L & 1] and writes its partial sums to slot L & 1.
+// ------------------------------------------------------------------------------------------
+struct LmShared {
+    double part[kFinThreads / 32][32];
+    double tot[32];
+    float  AtA[36], AtB[6], A[6][8], v[8], X[8], pose[8];
+    int    ended;
+    float  eA[6][6], eV[6][6], eVi[6][6], eV2[6][6], eW[6];      // iteration-0 analysis only
+    int    eR[6], eC[6];
+};
+
+// matAtA / matAtB / laserCloudSelNum of iteration `iter` from the partial sums of launch `iter`
+// (:1182-1239).  Ends with a workgroup barrier; returns laserCloudSelNum.
+template <int NT>
+__device__ __forceinline__ int lm_normal_eq(const DevCtx* __restrict__ cp, int iter, bool writer, LmShared& sh)
+{
+    constexpr int NG = NT / 32;                         // row groups
+    const auto st = G(cp->state);
+    const int t = threadIdx.x, col = t & 31, grp = t >> 5;
+    double s = 0.0;
+    if (col < kAcc) {
+        const int nbk = cp->nblocks;
+        const auto P = G((const double*)cp->partials) + (size_t)(iter & 1) * (size_t)nbk * kAcc;
+        const int nb = min(nbk, (*G(cp->n_waves) + (kBlock / 64) - 1) / (kBlock / 64));   // active workgroups
+        for (int b0 = grp; b0 < nb; b0 += 16 * NG) {    // 16 independent loads in flight per lane
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const int b = b0 + u * NG; v[u] = (b < nb) ? P[(size_t)b * kAcc + col] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
+    }
+    sh.part[grp][col] = s;
+    __syncthreads();
+    if (t < kAcc) {
+        double v = 0.0;
+#pragma unroll
+        for (int g2 = 0; g2 < NG; g2++) v += sh.part[g2][t];
+        sh.tot[t] = v;
+    }
+    __syncthreads();
+    // fp32 matrices (:1184-1186): entry (a, b), a <= b, is sum number a*6 - a(a-1)/2 + (b-a)
+    const int n_sel = (int)sh.tot[27];
+    if (t < 36) {
+        const int a = min(t / 6, t % 6), b = max(t / 6, t % 6);
+        const float v = (float)sh.tot[a * 6 - (a * (a - 1)) / 2 + (b - a)];
+        sh.AtA[t] = v;
+        if (writer) st->AtA[t] = v;
+    } else if (t < 42) {
+        const float v = (float)sh.tot[21 + (t - 36)];
+        sh.AtB[t - 36] = v;
+        if (writer) st->AtB[t - 36] = v;
+    }
+    if (writer && t == 0) st->n_sel_last = n_sel;
+    __syncthreads();
+    return n_sel;
+}
+
+// Solve, project, update, test (:1177-1180, :1240-1292) for iteration `iter` whose normal
+// equations are in `sh`.  `pose0` is the pose launch `iter` ran with.  All threads of the
+// workgroup call it; all return the updated pose in pose_out and whether the loop has ended
+// (converged with early exit on, or fewer than min_corr correspondences).  kFull adds the
+// iteration-0 degeneracy analysis on wave 1 (needs >= 2 waves).  `writer` records the outcome.
+template <bool kFull>
+__device__ __forceinline__ bool lm_solve_update(const DevCtx* __restrict__ cp, int iter, int n_sel, bool writer,
+                                                const float (&pose0)[6], int degen0, LmShared& sh, float (&pose_out)[6])
+{
+    const auto st = G(cp->state);
+    const auto trace = G(cp->trace);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+
+    if (n_sel < cp->min_corr) {                         // :1178-1180: false, pose unchanged
+        if (writer && t == 0) {
+            s2m_iter_trace tr;
+            tr.n_sel = n_sel; tr.stepped = 0; tr.deltaR = 0.0f; tr.deltaT = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { tr.pose[k] = pose0[k]; tr.delta[k] = 0.0f; st->pose[k] = pose0[k]; }
+            st->stalled = 1; st->done = 1;              // the remaining iterations repeat this no-op
+            st->iters_run = cp->max_iter;
+            store_trace(trace + iter, tr);
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) pose_out[k] = pose0[k];
+        return true;
+    }
+
+    // ---- wave 0: the QR solve on 7 lanes.  wave 1 (iteration 0 only): the degeneracy analysis.
+    if (wave == 0) {
+        float colv[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) colv[i] = (lane < 6) ? sh.AtA[i * 6 + lane] : ((lane == 6) ? sh.AtB[i] : 0.0f);
+        float X[6];
+        solve6_qr_lanes(lane, colv, sh.v, sh.A, X);     // :1240
+        if (lane == 6) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) sh.X[k] = X[k];
+        }
+    } else if (kFull && wave == 1 && lane == 0 && iter == 0) {   // :1242-1264
+        int degenerate = 0;
+        if (!all_eigen_above(sh.AtA, cp->eig_thresh)) {
+            // the full restatement: cv::eigen, the row-zeroing loop, matP = matV.inv() * matV2
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eA[i][j] = sh.AtA[i * 6 + j];
+            eigen6_sym(sh.eA, sh.eV, sh.eW, sh.eR, sh.eC);
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eV2[i][j] = sh.eV[i][j];
+            for (int i = 5; i >= 0; i--) {
+                if (sh.eW[i] < cp->eig_thresh) { for (int j = 0; j < 6; j++) sh.eV2[i][j] = 0.0f; degenerate = 1; }
+                else break;
+            }
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eA[i][j] = sh.eV[i][j];
+            inv6_lu(sh.eA, sh.eVi);
+            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {      // matP = matV.inv() * matV2
+                double a = 0.0;
+                for (int k = 0; k < 6; k++) a += (double)sh.eVi[i][k] * (double)sh.eV2[k][j];
+                st->matP[i * 6 + j] = (float)a;
+            }
+        }
+        // not degenerate: matP is never read before the next scan's iteration 0 rewrites it
+        st->isDegenerate = degenerate;
+        __threadfence_block();
+    }
+    __syncthreads();
+
+    // ---- thread 0: projection, pose update, convergence test (:1266-1292)
+    if (t == 0) {
+        float X[6], pose[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { X[k] = sh.X[k]; pose[k] = pose0[k]; }
+        if ((kFull && iter == 0) ? (st->isDegenerate != 0) : (degen0 != 0)) {   // :1266-1271 (iteration 0: just decided by wave 1)
+            float X2[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) X2[k] = X[k];
+            for (int i = 0; i < 6; i++) {
+                double a = 0.0;
+                for (int k = 0; k < 6; k++) a += (double)st->matP[i * 6 + k] * (double)X2[k];
+                X[i] = (float)a;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pose[k] += X[k]; sh.pose[k] = pose[k]; }  // :1273-1278
+        const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
+        const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);          // :1280-1283
+        const double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
+        const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);          // :1284-1287
+        const bool conv = ((double)deltaR < cp->conv_deg) && ((double)deltaT < cp->conv_cm);   // :1289
+        sh.ended = (conv && cp->early_exit) ? 1 : 0;                            // break (:1313-1314)
+        if (writer) {
+            s2m_iter_trace tr;
+            tr.n_sel = n_sel; tr.stepped = 1; tr.deltaR = deltaR; tr.deltaT = deltaT;
+#pragma unroll
+            for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; }
+            // launch iter+1 rebuilds its transform from this pose (k_register prologue)
+#pragma unroll
+            for (int k = 0; k < 6; k++) { st->pose[k] = pose[k]; st->pose2[(iter + 1) & 1][k] = pose[k]; }
+            st->T_valid = 0;
+            store_trace(trace + iter, tr);
+            st->iters_run = iter + 1;
+            if (conv && !st->converged) st->converged = 1;
+            if (conv && cp->early_exit) st->done = 1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose_out[k] = sh.pose[k];
+    return sh.ended != 0;
+}
+
 template <bool HOOK>
-__global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict__ cp)
+__global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict__ cp, int launch, int solve_prev)
 {
     constexpr int NW = kBlock / 64;
     const auto st = G((const DevState*)cp->state);
@@ -691,17 +1080,53 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     const int ablate = cp->ablate;
     const float gatef = cp->gate_f;
 
+    // everything that does not depend on the pose is requested first: it is in flight while the
+    // previous iteration is closed below
+    float px = 0.0f, py = 0.0f, pz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    v4f pm[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) pm[j] = v4f{ 0, 0, 0, 0 };
+    int pvalid = 0;
+    v4f pl_early = { 0, 0, 0, 0 };
+    int pst_early = 0;
+    if (valid) {
+#pragma unroll
+        for (int j = 0; j < 5; j++) pm[j] = prevp[(size_t)j * nq + i];
+        pvalid = G(cp->prior_valid)[i];
+        px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
+        pl_early = G((const v4f*)cp->plane_cache)[i];      // used if the neighbour tuple is unchanged
+        pst_early = G(cp->plane_state)[i];
+    }
+
     // transPointAssociateToMap (:1069-1072) and the LM trig (:1170-1175). Launch 0 of a scan gets them
-    // from the host (libm); later launches rebuild them from the pose k_finalize left behind: lanes
-    // 0..2 take one angle each (fp64 sincos rounded once to fp32), hidden behind the first loads.
+    // from the host (libm); later launches rebuild them from the pose: lanes 0..2 take one angle each
+    // (fp64 sincos rounded once to fp32).  With solve_prev the pose is first advanced by closing
+    // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.
     float T[12], sc6[6];
-    if (st->T_valid) {
+    if (!solve_prev && st->T_valid) {
 #pragma unroll
         for (int k = 0; k < 12; k++) T[k] = st->T[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) sc6[k] = st->sc[k];
     } else {
-        const float ang = st->pose[2 - min(lane, 2)];            // lane 0: yaw, 1: pitch, 2: roll
+        float pose[6];
+        if (solve_prev) {
+            static_assert(sizeof(LmShared) <= sizeof(v4f) * kTilePts * NW, "LM scratch must fit the tile area");
+            LmShared& sh = *reinterpret_cast<LmShared*>(&s_pts[0][0]);
+            const int degen0 = st->isDegenerate;
+            float pose0[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) pose0[k] = st->pose2[(launch - 1) & 1][k];
+            const bool writer = blockIdx.x == 0;
+            const int n_sel = lm_normal_eq<kBlock>(cp, launch - 1, writer, sh);
+            const bool ended = lm_solve_update<false>(cp, launch - 1, n_sel, writer, pose0, degen0, sh, pose);
+            __syncthreads();                               // the scratch is the waves' tile area again
+            if (ended) return;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) pose[k] = st->pose2[launch & 1][k];
+        }
+        const float ang = (lane == 0) ? pose[2] : ((lane == 1) ? pose[1] : pose[0]);   // lane 0: yaw, 1: pitch, 2+: roll
         double sn, cs;
         sincos((double)ang, &sn, &cs);
         const float snf = (float)sn, csf = (float)cs;
@@ -709,29 +1134,19 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
         const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 1)), C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 1));
         const float F = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 2)), E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 2));
         const float DE = D * E, DF = D * F;
-        T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = st->pose[3];
-        T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = st->pose[4];
-        T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = st->pose[5];
+        T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = pose[3];
+        T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = pose[4];
+        T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = pose[5];
         sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
     }
 
-    float px = 0.0f, py = 0.0f, pz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
     Top5 best;
 #pragma unroll
     for (int k = 0; k < 5; k++) { best.key[k] = kKeyInf; best.x[k] = 0.0f; best.y[k] = 0.0f; best.z[k] = 0.0f; }
     float bound = gatef;
     int pidx[5] = { -1, -1, -1, -1, -1 };
-    v4f pl_early = { 0, 0, 0, 0 };
-    int pst_early = 0;
 
     if (valid) {
-        v4f pm[5];
-#pragma unroll
-        for (int j = 0; j < 5; j++) pm[j] = prevp[(size_t)j * nq + i];
-        const int pvalid = G(cp->prior_valid)[i];
-        px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
-        pl_early = G((const v4f*)cp->plane_cache)[i];      // in flight during the search (used if the tuple is unchanged)
-        pst_early = G(cp->plane_state)[i];
         // pointAssociateToMap (:302-308), association order of the reference expression
         sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
         sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
@@ -1125,7 +1540,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     // hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
     // five steps lane l holds, in acc[0], sum number l>>1 over its half-wave pair group, and one
     // full exchange with lane^1 completes it.  Fixed order: bitwise reproducible.
-    if (ablate & 4) { if (tid < kAcc) G(cp->partials)[(size_t)blockIdx.x * kAcc + tid] = acc[0] + acc[27]; return; }
+    const auto partial_row = G(cp->partials) + ((size_t)(launch & 1) * (size_t)cp->nblocks + blockIdx.x) * kAcc;   // slot launch & 1
+    if (ablate & 4) { if (tid < kAcc) partial_row[tid] = acc[0] + acc[27]; return; }
 #pragma unroll
     for (int h = 16, m = 32; h >= 1; h >>= 1, m >>= 1) {
         const bool up = (lane & m) != 0;
@@ -1149,450 +1565,30 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
         double s = red[0][tid];
 #pragma unroll
         for (int w = 1; w < NW; w++) s += red[w][tid];
-        G(cp->partials)[(size_t)blockIdx.x * kAcc + tid] = s;
+        partial_row[tid] = s;
     }
 #undef S2M_LAP
 }
 
 // ------------------------------------------------------------------------------------------
-// 6x6 algebra of LMOptimization (:1237-1271) for one lane
-// ------------------------------------------------------------------------------------------
-// cv::solve(matAtA, matAtB, matX, DECOMP_QR) (:1240): un-pivoted Householder QR in fp32 with
-// unit-length reflectors, rhs transformed, back substitution (OpenCV >= 3.3 hal::QR32f).
-__device__ bool solve6_qr(const float (&Ain)[36], const float (&bin)[6], float (&x)[6])
-{
-    float A[6][6], b[6], hf[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        b[i] = bin[i];
-#pragma unroll
-        for (int j = 0; j < 6; j++) A[i][j] = Ain[i * 6 + j];
-    }
-#pragma unroll
-    for (int l = 0; l < 6; l++) {
-        float vl[6];
-        float nrm = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 6 - l; i++) { vl[i] = A[l + i][l]; nrm += vl[i] * vl[i]; }
-        const float tmpV = vl[0];
-        vl[0] = vl[0] + (vl[0] >= 0.0f ? 1.0f : -1.0f) * sqrtf(nrm);
-        nrm = sqrtf(nrm + vl[0] * vl[0] - tmpV * tmpV);
-#pragma unroll
-        for (int i = 0; i < 6 - l; i++) vl[i] /= nrm;
-#pragma unroll
-        for (int j = l; j < 6; j++) {
-            float v = 0.0f;
-#pragma unroll
-            for (int i = l; i < 6; i++) v += vl[i - l] * A[i][j];
-#pragma unroll
-            for (int i = l; i < 6; i++) A[i][j] -= 2.0f * vl[i - l] * v;
-        }
-        hf[l] = vl[0] * vl[0];
-#pragma unroll
-        for (int i = 1; i < 6 - l; i++) A[l + i][l] = vl[i] / vl[0];
-    }
-#pragma unroll
-    for (int l = 0; l < 6; l++) {
-        float vl[6];
-        vl[0] = 1.0f;
-#pragma unroll
-        for (int j = 1; j < 6 - l; j++) vl[j] = A[j + l][l];
-        float v = 0.0f;
-#pragma unroll
-        for (int i = l; i < 6; i++) v += vl[i - l] * b[i];
-#pragma unroll
-        for (int i = l; i < 6; i++) b[i] -= 2.0f * vl[i - l] * v * hf[l];
-    }
-    bool ok = true;
-#pragma unroll
-    for (int i = 5; i >= 0; i--) {
-#pragma unroll
-        for (int j = 5; j > i; j--) b[i] -= b[j] * A[i][j];
-        if (fabsf(A[i][i]) < FLT_EPSILON * 10.0f) ok = false;
-        b[i] /= A[i][i];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) x[i] = ok ? b[i] : 0.0f;
-    return ok;
-}
-
-// cv::eigen (:1248): max-pivot Jacobi in fp32, eigenvalues descending, eigenvectors as rows.
-// A and V are LDS scratch of the calling lane (data-dependent indexing).
-__device__ void eigen6_sym(float (*A)[6], float (*V)[6], float* W, int* indR, int* indC)
-{
-    constexpr int N = 6;
-    const float eps = FLT_EPSILON;
-    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) V[i][j] = (i == j) ? 1.0f : 0.0f;
-    for (int k = 0; k < N; k++) {
-        W[k] = A[k][k];
-        if (k < N - 1) {
-            int m = k + 1; float mv = fabsf(A[k][m]);
-            for (int i = k + 2; i < N; i++) { float v = fabsf(A[k][i]); if (mv < v) { mv = v; m = i; } }
-            indR[k] = m;
-        }
-        if (k > 0) {
-            int m = 0; float mv = fabsf(A[0][k]);
-            for (int i = 1; i < k; i++) { float v = fabsf(A[i][k]); if (mv < v) { mv = v; m = i; } }
-            indC[k] = m;
-        }
-    }
-    for (int it = 0; it < N * N * 30; it++) {
-        int k = 0, l; float mv = fabsf(A[0][indR[0]]);
-        for (int i = 1; i < N - 1; i++) { float v = fabsf(A[i][indR[i]]); if (mv < v) { mv = v; k = i; } }
-        l = indR[k];
-        for (int i = 1; i < N; i++) { float v = fabsf(A[indC[i]][i]); if (mv < v) { mv = v; k = indC[i]; l = i; } }
-        const float p = A[k][l];
-        if (fabsf(p) <= eps) break;
-        const float y = (W[l] - W[k]) * 0.5f;
-        float t = fabsf(y) + hypotf(p, y);
-        float s = hypotf(p, t);
-        const float c = t / s;
-        s = p / s; t = (p / t) * p;
-        if (y < 0.0f) { s = -s; t = -t; }
-        A[k][l] = 0.0f;
-        W[k] -= t; W[l] += t;
-#define S2M_ROT(v0, v1) do { const float a0 = (v0), b0 = (v1); (v0) = a0 * c - b0 * s; (v1) = a0 * s + b0 * c; } while (0)
-        for (int i = 0; i < k; i++)     S2M_ROT(A[i][k], A[i][l]);
-        for (int i = k + 1; i < l; i++) S2M_ROT(A[k][i], A[i][l]);
-        for (int i = l + 1; i < N; i++) S2M_ROT(A[k][i], A[l][i]);
-        for (int i = 0; i < N; i++)     S2M_ROT(V[k][i], V[l][i]);
-#undef S2M_ROT
-        for (int j = 0; j < 2; j++) {
-            const int idx = j == 0 ? k : l;
-            if (idx < N - 1) {
-                int m = idx + 1; float mv2 = fabsf(A[idx][m]);
-                for (int i = idx + 2; i < N; i++) { float v = fabsf(A[idx][i]); if (mv2 < v) { mv2 = v; m = i; } }
-                indR[idx] = m;
-            }
-            if (idx > 0) {
-                int m = 0; float mv2 = fabsf(A[0][idx]);
-                for (int i = 1; i < idx; i++) { float v = fabsf(A[i][idx]); if (mv2 < v) { mv2 = v; m = i; } }
-                indC[idx] = m;
-            }
-        }
-    }
-    for (int k = 0; k < N - 1; k++) {
-        int m = k;
-        for (int i = k + 1; i < N; i++) if (W[m] < W[i]) m = i;
-        if (k != m) {
-            float tw = W[m]; W[m] = W[k]; W[k] = tw;
-            for (int i = 0; i < N; i++) { float tv = V[m][i]; V[m][i] = V[k][i]; V[k][i] = tv; }
-        }
-    }
-}
-
-// cv::Mat::inv() (:1263): LU with partial pivoting applied to [A | I], fp32. A is destroyed.
-__device__ bool inv6_lu(float (*A)[6], float (*B)[6])
-{
-    constexpr int N = 6;
-    const float eps = FLT_EPSILON * 10.0f;
-    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) B[i][j] = (i == j) ? 1.0f : 0.0f;
-    for (int i = 0; i < N; i++) {
-        int k = i;
-        for (int j = i + 1; j < N; j++) if (fabsf(A[j][i]) > fabsf(A[k][i])) k = j;
-        if (fabsf(A[k][i]) < eps) {
-            for (int a = 0; a < N; a++) for (int b = 0; b < N; b++) B[a][b] = 0.0f;
-            return false;
-        }
-        if (k != i) {
-            for (int j = i; j < N; j++) { float t = A[i][j]; A[i][j] = A[k][j]; A[k][j] = t; }
-            for (int j = 0; j < N; j++) { float t = B[i][j]; B[i][j] = B[k][j]; B[k][j] = t; }
-        }
-        const float d = -1.0f / A[i][i];
-        for (int j = i + 1; j < N; j++) {
-            const float alpha = A[j][i] * d;
-            for (int m = i + 1; m < N; m++) A[j][m] += alpha * A[i][m];
-            for (int m = 0; m < N; m++) B[j][m] += alpha * B[i][m];
-        }
-    }
-    for (int i = N - 1; i >= 0; i--)
-        for (int j = 0; j < N; j++) {
-            float s = B[i][j];
-            for (int k = i + 1; k < N; k++) s -= A[i][k] * B[k][j];
-            B[i][j] = s / A[i][i];
-        }
-    return true;
-}
-
-// pcl::getTransformation via trans2Affine3f (:348-351) plus the six sin/cos of :1170-1175.
-// sin/cos are evaluated in fp64 and rounded once to fp32 (device sinf/cosf are a few ulp off
-// libm's; the double-rounded value agrees with a correctly rounded fp32 libm result).
-__device__ void pose_to_transform(const float (&t)[6], float* T, float* sc)
-{
-    const float A = (float)cos((double)t[2]), B = (float)sin((double)t[2]);
-    const float C = (float)cos((double)t[1]), D = (float)sin((double)t[1]);
-    const float E = (float)cos((double)t[0]), F = (float)sin((double)t[0]);
-    const float DE = D * E, DF = D * F;
-    T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = t[3];
-    T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = t[4];
-    T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = t[5];
-    sc[0] = B; sc[1] = A; sc[2] = D; sc[3] = C; sc[4] = F; sc[5] = E;
-}
-
-// ------------------------------------------------------------------------------------------
-// k_finalize: second stage of the AtA/AtB reduction (fixed order: bitwise reproducible for a
-// given workgroup partition) and, by lane 0, the rest of LMOptimization (:1177-1292): the
-// 6x6 solve, the iteration-0 degeneracy analysis, the pose update and the convergence test.
-// It leaves the next iteration's transform in DevState, so the 30-iteration loop (:1304-1315)
-// never returns to the host.  mode 1 = normal equations only (observation hook).
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void store_trace(gptr<s2m_iter_trace> dst, const s2m_iter_trace& tr)
-{
-    dst->n_sel = tr.n_sel; dst->stepped = tr.stepped; dst->deltaR = tr.deltaR; dst->deltaT = tr.deltaT;
-#pragma unroll
-    for (int k = 0; k < 6; k++) { dst->delta[k] = tr.delta[k]; dst->pose[k] = tr.pose[k]; }
-}
-
-// cv::solve(matAtA, matAtB, matX, DECOMP_QR) (:1240) spread over 7 lanes of one wave: lane j < 6
-// owns column j of AtA, lane 6 the right-hand side.  Per reflector l: lane l builds the unit vector
-// (the only serial part: two sqrt, 6-l divides), every owner updates its own column, lane 6
-// applies the stored form of the reflector to b.  Each number goes through exactly the
-// operations, in the order, of the single-lane solve6_qr() above.  `sv` is 8 floats of LDS.
-__device__ __forceinline__ bool solve6_qr_lanes(int lane, float (&col)[6], float* sv, float (*sA)[8], float (&x)[6])
-{
-#pragma unroll
-    for (int l = 0; l < 6; l++) {
-        if (lane == l) {
-            float vl[6];
-            float nrm = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 6 - l; i++) { vl[i] = col[l + i]; nrm += vl[i] * vl[i]; }
-            const float tmpV = vl[0];
-            vl[0] = vl[0] + (vl[0] >= 0.0f ? 1.0f : -1.0f) * sqrtf(nrm);
-            nrm = sqrtf(nrm + vl[0] * vl[0] - tmpV * tmpV);
-#pragma unroll
-            for (int i = 0; i < 6 - l; i++) { vl[i] /= nrm; sv[i] = vl[i]; }
-        }
-        wave_lds_sync();
-        float vl[6];
-#pragma unroll
-        for (int i = 0; i < 6 - l; i++) vl[i] = sv[i];
-        if (lane >= l && lane < 6) {
-            float v = 0.0f;
-#pragma unroll
-            for (int i = l; i < 6; i++) v += vl[i - l] * col[i];
-#pragma unroll
-            for (int i = l; i < 6; i++) col[i] -= 2.0f * vl[i - l] * v;
-            if (lane == l) {
-#pragma unroll
-                for (int i = 1; i < 6 - l; i++) col[l + i] = vl[i] / vl[0];
-            }
-        } else if (lane == 6) {
-            const float hf = vl[0] * vl[0];
-            float u[6];
-            u[0] = 1.0f;
-#pragma unroll
-            for (int i = 1; i < 6 - l; i++) u[i] = vl[i] / vl[0];
-            float v = 0.0f;
-#pragma unroll
-            for (int i = l; i < 6; i++) v += u[i - l] * col[i];
-#pragma unroll
-            for (int i = l; i < 6; i++) col[i] -= 2.0f * u[i - l] * v * hf;
-        }
-        wave_lds_sync();
-    }
-    if (lane < 7) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) sA[i][lane] = col[i];
-    }
-    wave_lds_sync();
-    bool ok = true;
-    float b[6];
-#pragma unroll
-    for (int i = 0; i < 6; i++) b[i] = sA[i][6];
-#pragma unroll
-    for (int i = 5; i >= 0; i--) {
-#pragma unroll
-        for (int j = 5; j > i; j--) b[i] -= b[j] * sA[i][j];
-        if (fabsf(sA[i][i]) < FLT_EPSILON * 10.0f) ok = false;
-        b[i] /= sA[i][i];
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) x[i] = ok ? b[i] : 0.0f;
-    return ok;
-}
-
-// Is every eigenvalue of the symmetric 6x6 A safely above `thresh`?  Cholesky of A - s*I in
-// fp64 with s = thresh + margin, margin = 1e-5 * trace(A) (far above the fp32 Jacobi's error of a
-// few ulp of the largest eigenvalue, far below any eigenvalue that matters): if it succeeds,
-// cv::eigen would report all six eigenvalues >= thresh and isDegenerate stays false (:1251-1262).
-__device__ bool all_eigen_above(const float* A, float thresh)
-{
-    double tr = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) tr += (double)A[i * 6 + i];
-    if (!(tr > 0.0) || !(tr < 1.0e30)) return false;
-    const double sft = (double)thresh + 1e-5 * tr;
-    double L[6][6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-        double d = (double)A[j * 6 + j] - sft;
-#pragma unroll
-        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k];
-        if (!(d > 1e-9 * tr)) return false;
-        const double dj = sqrt(d);
-        L[j][j] = dj;
-#pragma unroll
-        for (int i = j + 1; i < 6; i++) {
-            double v = (double)A[i * 6 + j];
-#pragma unroll
-            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
-            L[i][j] = v / dj;
-        }
-    }
-    return true;
-}
-
-// ------------------------------------------------------------------------------------------
-// k_finalize: second stage of the AtA/AtB reduction (fixed order: bitwise reproducible for a
-// given workgroup partition) and the rest of LMOptimization (:1177-1292): the 6x6 solve, the
-// iteration-0 degeneracy analysis, the pose update and the convergence test.  It leaves the
-// next iteration's transform in DevState, so the 30-iteration loop (:1304-1315) never returns
-// to the host.  The scalar algebra is spread over a few lanes of wave 0 (QR columns, the three
-// sin/cos pairs) while wave 1 settles the degeneracy question.  mode 1 = normal equations only.
+// k_finalize: one workgroup closing iteration `iter` on its own (see lm_normal_eq /
+// lm_solve_update above): iteration 0 with the degeneracy analysis, and the last iteration of a
+// scan.  mode 1 = normal equations only (observation hook).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restrict__ cp, int iter, int mode)
 {
     const auto st = G(cp->state);
-    const auto trace = G(cp->trace);
     // loop state, fetched up front so that it is in flight together with the partial sums
     const int done0 = st->done, degen0 = st->isDegenerate;
     float pose0[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) pose0[k] = st->pose[k];
+    for (int k = 0; k < 6; k++) pose0[k] = st->pose2[iter & 1][k];
     if (mode == 0 && done0) return;
-
-    __shared__ double part[kFinThreads / 32][32];
-    __shared__ double tot[32];
-    __shared__ float sAtA[36], sAtB[6], sA[6][8], sv[8], sX[8], sPose[8];
-    __shared__ float eA[6][6], eV[6][6], eVi[6][6], eV2[6][6], eW[6];
-    __shared__ int eR[6], eC[6];
-
-    constexpr int NG = kFinThreads / 32;                // row groups
-    const int t = threadIdx.x, col = t & 31, grp = t >> 5, lane = t & 63, wave = t >> 6;
-    double s = 0.0;
-    if (col < kAcc) {
-        const auto P = G((const double*)cp->partials);
-        const int nb = min(cp->nblocks, (*G(cp->n_waves) + (kBlock / 64) - 1) / (kBlock / 64));   // active workgroups
-        for (int b0 = grp; b0 < nb; b0 += 16 * NG) {    // 16 independent loads in flight per lane
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) { const int b = b0 + u * NG; v[u] = (b < nb) ? P[(size_t)b * kAcc + col] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 16; u++) s += v[u];
-        }
-    }
-    part[grp][col] = s;
-    __syncthreads();
-    if (t < kAcc) {
-        double v = 0.0;
-#pragma unroll
-        for (int g2 = 0; g2 < NG; g2++) v += part[g2][t];
-        tot[t] = v;
-    }
-    __syncthreads();
-
-    // matAtA / matAtB in fp32 (:1184-1186): entry (a, b), a <= b, is sum number a*6 - a(a-1)/2 + (b-a)
-    const int n_sel = (int)tot[27];
-    if (t < 36) {
-        const int a = min(t / 6, t % 6), b = max(t / 6, t % 6);
-        const float v = (float)tot[a * 6 - (a * (a - 1)) / 2 + (b - a)];
-        sAtA[t] = v; st->AtA[t] = v;
-    } else if (t < 42) {
-        const float v = (float)tot[21 + (t - 36)];
-        sAtB[t - 36] = v; st->AtB[t - 36] = v;
-    }
-    if (t == 0) st->n_sel_last = n_sel;
+    __shared__ LmShared sh;
+    const int n_sel = lm_normal_eq<kFinThreads>(cp, iter, true, sh);
     if (mode == 1) return;
-    __syncthreads();
-
-    if (n_sel < cp->min_corr) {                         // :1178-1180: false, pose unchanged;
-        if (t == 0) {
-            s2m_iter_trace tr;
-            tr.n_sel = n_sel; tr.stepped = 0; tr.deltaR = 0.0f; tr.deltaT = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { tr.pose[k] = pose0[k]; tr.delta[k] = 0.0f; }
-            st->stalled = 1; st->done = 1;              // the remaining iterations repeat this no-op
-            st->iters_run = cp->max_iter;
-            store_trace(trace + iter, tr);
-        }
-        return;
-    }
-
-    // ---- wave 0: the QR solve on 7 lanes.  wave 1 (iteration 0 only): the degeneracy analysis.
-    if (wave == 0) {
-        float colv[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++) colv[i] = (lane < 6) ? sAtA[i * 6 + lane] : ((lane == 6) ? sAtB[i] : 0.0f);
-        float X[6];
-        solve6_qr_lanes(lane, colv, sv, sA, X);         // :1240
-        if (lane == 6) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) sX[k] = X[k];
-        }
-    } else if (wave == 1 && lane == 0 && iter == 0) {   // :1242-1264
-        int degenerate = 0;
-        if (!all_eigen_above(sAtA, cp->eig_thresh)) {
-            // the full restatement: cv::eigen, the row-zeroing loop, matP = matV.inv() * matV2
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eA[i][j] = sAtA[i * 6 + j];
-            eigen6_sym(eA, eV, eW, eR, eC);
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eV2[i][j] = eV[i][j];
-            for (int i = 5; i >= 0; i--) {
-                if (eW[i] < cp->eig_thresh) { for (int j = 0; j < 6; j++) eV2[i][j] = 0.0f; degenerate = 1; }
-                else break;
-            }
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) eA[i][j] = eV[i][j];
-            inv6_lu(eA, eVi);
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {      // matP = matV.inv() * matV2
-                double a = 0.0;
-                for (int k = 0; k < 6; k++) a += (double)eVi[i][k] * (double)eV2[k][j];
-                st->matP[i * 6 + j] = (float)a;
-            }
-        }
-        // not degenerate: matP is never read before the next scan's iteration 0 rewrites it
-        st->isDegenerate = degenerate;
-        __threadfence_block();
-    }
-    __syncthreads();
-
-    // ---- lane 0: projection, pose update, convergence test (:1266-1292)
-    s2m_iter_trace tr;
-    bool conv = false;
-    if (t == 0) {
-        float X[6], pose[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) { X[k] = sX[k]; pose[k] = pose0[k]; }
-        if ((iter == 0) ? (st->isDegenerate != 0) : (degen0 != 0)) {   // :1266-1271 (iteration 0: just decided by wave 1)
-            float X2[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) X2[k] = X[k];
-            for (int i = 0; i < 6; i++) {
-                double a = 0.0;
-                for (int k = 0; k < 6; k++) a += (double)st->matP[i * 6 + k] * (double)X2[k];
-                X[i] = (float)a;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) { pose[k] += X[k]; sPose[k] = pose[k]; }   // :1273-1278
-        const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
-        const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);          // :1280-1283
-        const double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
-        const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);          // :1284-1287
-        conv = ((double)deltaR < cp->conv_deg) && ((double)deltaT < cp->conv_cm);   // :1289
-        tr.n_sel = n_sel; tr.stepped = 1; tr.deltaR = deltaR; tr.deltaT = deltaT;
-#pragma unroll
-        for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; }
-    }
-    if (t == 0) {
-        // the next launch rebuilds its transform from this pose (k_register prologue)
-#pragma unroll
-        for (int k = 0; k < 6; k++) st->pose[k] = sPose[k];
-        st->T_valid = 0;
-        store_trace(trace + iter, tr);
-        st->iters_run = iter + 1;
-        if (conv && !st->converged) st->converged = 1;
-        if (conv && cp->early_exit) st->done = 1;       // break (:1313-1314)
-    }
+    float pose[6];
+    lm_solve_update<true>(cp, iter, n_sel, true, pose0, degen0, sh, pose);
 }
 
 // Parameter blocks travel as kernel arguments (copied at launch), so the host never has to

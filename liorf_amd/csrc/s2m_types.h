@@ -23,9 +23,10 @@ struct GridDesc {
     int   ncells;
 };
 
-// Per-scan loop state, lives in device memory; written only by the finalize kernel.
+// Per-scan loop state, lives in device memory; written by k_finalize and by workgroup 0 of k_register.
 struct DevState {
-    float pose[6];        // transformTobeMapped                (reference :134)
+    float pose[6];        // transformTobeMapped                (reference :134): latest value, read by the host
+    float pose2[2][6];    // pose launch L runs with, in slot L & 1 (double-buffered: see lm_solve_update)
     float T[12];          // transPointAssociateToMap, row-major (:142)
     float sc[6];          // srx,crx,sry,cry,srz,crz             (:1170-1175)
     float matP[36];       // degeneracy projector                (:140)
@@ -37,7 +38,7 @@ struct DevState {
     int32_t iters_run;
     int32_t n_sel_last;
     int32_t stalled;      // n_sel < min_corr: every further iteration is the same no-op
-    int32_t T_valid;      // 1: T/sc were set by the host for this pose; 0: k_register rebuilds them from pose
+    int32_t T_valid;      // 1: T/sc were set by the host (launch 0); 0: k_register rebuilds them from pose2
 };
 
 // Everything a kernel needs, in device memory so a captured graph stays valid when
@@ -55,7 +56,7 @@ struct DevCtx {
     int32_t n_q, n_m, nblocks;
     const int2* wave_table;       // [nblocks*4] {first sorted point, count <= 64} per wave
     const int32_t* n_waves;       // entries of wave_table in use
-    double* partials;             // [nblocks][kAcc]
+    double* partials;             // [2][nblocks][kAcc], slot = launch parity
     DevState* state;
     s2m_iter_trace* trace;        // [kMaxIter]
     // parameters
