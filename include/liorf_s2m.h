@@ -168,6 +168,10 @@ int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float*
  * per-iteration registration kernel (k_register: kNN + plane + Jacobian + block reduction);
  * returns the mean duration of those launches in ms. */
 int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float* ms_per_launch);
+/* Same measurement, reported per LM iteration: ms_per_iter[it] = mean duration of launch `it` of the
+ * loop over `reps` loops (cap >= max_iter entries). The first launches of a scan search without a prior
+ * and cost more than the steady state. */
+int  s2m_time_iterations(s2m_handle h, const float pose[6], int reps, float* ms_per_iter, int cap);
 
 /* Diagnostics: `launches` k_register passes at `pose` (the last one is recorded; 1 = the pass that
  * inherits its prior from whatever ran before, 3 = steady state at this pose); per wave (64 locality-sorted scan points) 16 words:

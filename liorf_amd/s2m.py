@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device",
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
-    "s2m_time_iteration_kernel", "s2m_make_scancontext", "s2m_debug_wave_profile",
+    "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
     "s2m_transform_cloud",
 ]
@@ -116,6 +116,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_normal_eq.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_int32)]
     L.s2m_last_timing.argtypes = [vp, fp, fp, fp]
     L.s2m_time_iteration_kernel.argtypes = [vp, fp, C.c_int, fp]
+    L.s2m_time_iterations.argtypes = [vp, fp, C.c_int, fp, C.c_int]
     L.s2m_debug_wave_profile.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint64), C.c_size_t]
     L.s2m_make_scancontext.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     szp = C.POINTER(C.c_size_t)
@@ -362,6 +363,13 @@ class MapOptimizationS2M:
         ms = C.c_float(0)
         self._check(self.lib.s2m_time_iteration_kernel(self.h, _fp(p), reps, C.byref(ms)), "s2m_time_iteration_kernel")
         return ms.value
+
+    def time_iterations(self, pose, reps: int = 10) -> np.ndarray:
+        """Mean k_register duration (ms) of every launch of the loop, index = LM iteration."""
+        p = np.ascontiguousarray(pose, np.float32)
+        out = np.zeros(64, np.float32)
+        self._check(self.lib.s2m_time_iterations(self.h, _fp(p), reps, _fp(out), 64), "s2m_time_iterations")
+        return out[:self.params.max_iter]
 
     def wave_profile(self, pose, launches: int = 3) -> np.ndarray:
         """Diagnostics: (n_waves, 16) uint64 per-wave stamps/stats of one k_register pass."""

@@ -303,3 +303,25 @@ def test_loop_parity_after_map_and_scan_changes(gpu, cfg_tiny, cfg_small):
         ro = orc.scan2MapOptimization(p2)
         assert r.iters_run == ro.iters_run
         assert np.abs(np.array(r.pose) - np.array(ro.pose)).max() <= 1e-4
+
+
+def test_fused_and_plain_loop_agree(cfg_small, monkeypatch):
+    """The loop with iterations closed inside the next k_register launch (default for co-resident grids)
+    against one k_finalize per iteration (S2M_NO_FUSE=1): same trace, early exit on and off."""
+    m, s = synth.to_xyzi(cfg_small["map"]), synth.to_xyzi(cfg_small["scan"])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("S2M_NO_FUSE", mode)
+        for early in (1, 0):
+            g = s2m.MapOptimizationS2M(early_exit=early)
+            g.setInputCloud(m)
+            r = g.optimize(s, cfg_small["pose_init"])
+            out[(mode, early)] = (r.iters_run, r.converged, r.n_sel_last, np.array(r.pose),
+                                  np.array([t.pose[:] for t in g.trace()]), np.array([t.n_sel for t in g.trace()]))
+            g.close()
+    for early in (1, 0):
+        a, b = out[("0", early)], out[("1", early)]
+        assert a[:3] == b[:3]
+        assert np.array_equal(a[5], b[5])
+        assert np.abs(a[3] - b[3]).max() <= 1e-6 and np.abs(a[4] - b[4]).max() <= 1e-6
+    assert out[("0", 1)][0] < 30 and out[("0", 0)][0] == 30
