@@ -272,24 +272,22 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     if ((rc = ensure(h, h->prevp, sizeof(float4) * 5 * n))) return rc;
     if ((rc = ensure(h, h->plane_cache, sizeof(float4) * n))) return rc;
     if ((rc = ensure(h, h->plane_state, sizeof(int32_t) * n))) return rc;
-    S2M_HIP(h, hipMemsetAsync(h->plane_state.p, 0, sizeof(int32_t) * n, h->stream));
-    if ((rc = ensure(h, h->prior_valid, sizeof(int32_t) * n))) return rc;
-    S2M_HIP(h, hipMemsetAsync(h->prior_valid.p, 0, sizeof(int32_t) * n, h->stream));     // no prior for a new scan
-    if ((rc = ensure(h, h->q_counts, sizeof(int32_t) * kPolarCells))) return rc;
+    if ((rc = ensure(h, h->prior_valid, sizeof(int32_t) * n))) return rc;     // both are reset by k_scatter_scan
     if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
     if ((rc = ensure(h, h->q_rank_of, sizeof(int32_t) * n))) return rc;
 
-    S2M_HIP(h, hipMemsetAsync(h->q_counts.p, 0, sizeof(int32_t) * kPolarCells, h->stream));
     const int nb = ((int)n + 255) / 256;
-    hipLaunchKernelGGL(k_polar_count, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
+    // q_counts is all zero here: cleared at creation and again by every k_polar_scan
+    hipLaunchKernelGGL(k_polar_count, dim3(((int)n + kPolarBlock - 1) / kPolarBlock), dim3(kPolarBlock), 0, h->stream, d_pts, stride, (int)n,
                        h->q_cell_of.as<int32_t>(), h->q_rank_of.as<int32_t>(), h->q_counts.as<int32_t>());
     hipLaunchKernelGGL(k_polar_scan, dim3(1), dim3(1024), 0, h->stream,
-                       (const int32_t*)h->q_counts.as<int32_t>(), h->q_cell_start.as<int32_t>());
+                       h->q_counts.as<int32_t>(), h->q_cell_start.as<int32_t>());
     hipLaunchKernelGGL(k_scatter_scan, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
                        (const int32_t*)h->q_cell_of.as<int32_t>(), (const int32_t*)h->q_rank_of.as<int32_t>(),
                        (const int32_t*)h->q_cell_start.as<int32_t>(),
-                       h->qx.as<float>(), h->qy.as<float>(), h->qz.as<float>(), h->qperm.as<int32_t>());
+                       h->qx.as<float>(), h->qy.as<float>(), h->qz.as<float>(), h->qperm.as<int32_t>(),
+                       h->prior_valid.as<int32_t>(), h->plane_state.as<int32_t>());
     S2M_HIP(h, hipGetLastError());
 
     h->hctx.qx = h->qx.as<float>(); h->hctx.qy = h->qy.as<float>(); h->hctx.qz = h->qz.as<float>();
@@ -492,8 +490,10 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (ensure(h, h->state, sizeof(DevState)) || ensure(h, h->trace, sizeof(s2m_iter_trace) * kMaxIter) ||
         ensure(h, h->dctx, sizeof(DevCtx)) || ensure(h, h->mm, 64) ||
         ensure(h, h->partials, sizeof(double) * 2 * kAcc * kBlocksQuantum) ||
-        ensure(h, h->sc_bins, sizeof(uint32_t) * 1200) || ensure(h, h->sc_out, sizeof(double) * 1220))
+        ensure(h, h->sc_bins, sizeof(uint32_t) * 1200) || ensure(h, h->sc_out, sizeof(double) * 1220) ||
+        ensure(h, h->q_counts, sizeof(int32_t) * kPolarCells))
         return bail(S2M_ERR_HIP);
+    if (hipMemsetAsync(h->q_counts.p, 0, sizeof(int32_t) * kPolarCells, h->stream) != hipSuccess) return bail(S2M_ERR_HIP);
 
     if (!(h->vox = vox_create())) return bail(S2M_ERR_HIP);
 

@@ -123,29 +123,49 @@ __device__ __forceinline__ int polar_cell(float x, float y)
     return (int)hilbert128((uint32_t)ab, (uint32_t)rb);
 }
 
-__global__ void k_polar_count(const unsigned char* __restrict__ pts, size_t stride, int n,
-                              int32_t* __restrict__ cell_of, int32_t* __restrict__ rank_of,
-                              int32_t* __restrict__ counts)
+// Histogram with per-point rank.  Device-scope returning atomics are served memory-side on this
+// multi-die part (~27 us for 120 k of them), so every workgroup of 1024 points first ranks its
+// points in an LDS histogram and then reserves one range per non-empty cell with a single global
+// atomic: consecutive input points (acquisition order, or the voxel filter's x-rows) share cells,
+// which cuts the global atomics by an order of magnitude.
+constexpr int kPolarBlock = 1024;
+__global__ __launch_bounds__(kPolarBlock) void k_polar_count(const unsigned char* __restrict__ pts, size_t stride, int n,
+                                                             int32_t* __restrict__ cell_of, int32_t* __restrict__ rank_of,
+                                                             int32_t* __restrict__ counts)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
-    const int c = polar_cell(p[0], p[1]);
-    cell_of[i] = c;
-    rank_of[i] = atomicAdd(&counts[c], 1);
+    __shared__ int32_t hist[kPolarCells];
+    const int t = threadIdx.x;
+    for (int k = t; k < kPolarCells; k += kPolarBlock) hist[k] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * kPolarBlock + t;
+    int c = 0, r = 0;
+    if (i < n) {
+        const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
+        c = polar_cell(p[0], p[1]);
+        r = atomicAdd(&hist[c], 1);
+    }
+    __syncthreads();
+    for (int k = t; k < kPolarCells; k += kPolarBlock) {
+        const int cnt = hist[k];
+        if (cnt) hist[k] = atomicAdd(&counts[k], cnt);          // first rank of this workgroup's points in cell k
+    }
+    __syncthreads();
+    if (i < n) { cell_of[i] = c; rank_of[i] = hist[c] + r; }
 }
 
-// exclusive scan of the 16384 polar cell counts by one workgroup (16 per thread)
-__global__ __launch_bounds__(1024) void k_polar_scan(const int32_t* __restrict__ counts, int32_t* __restrict__ start)
+// exclusive scan of the 16384 polar cell counts by one workgroup (16 per thread); the counts are
+// zeroed as they are read, ready for the next scan
+__global__ __launch_bounds__(1024) void k_polar_scan(int32_t* __restrict__ counts, int32_t* __restrict__ start)
 {
     __shared__ int32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int32_t v[16];
     int32_t sum = 0;
-    const int4* c4 = reinterpret_cast<const int4*>(counts + t * 16);
+    int4* c4 = reinterpret_cast<int4*>(counts + t * 16);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int4 q = c4[k];
+        c4[k] = make_int4(0, 0, 0, 0);
         v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
         sum += q.x + q.y + q.z + q.w;
     }
@@ -269,13 +289,16 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
                                const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
                                const int32_t* __restrict__ cell_start,
                                float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz,
-                               int32_t* __restrict__ qperm)
+                               int32_t* __restrict__ qperm, int32_t* __restrict__ prior_valid,
+                               int32_t* __restrict__ plane_state)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
     int pos = cell_start[cell_of[i]] + rank_of[i];
+    if ((unsigned)pos >= (unsigned)n) return;            // cannot happen while the histogram is consistent
     qx[pos] = p[0]; qy[pos] = p[1]; qz[pos] = p[2]; qperm[pos] = i;
+    prior_valid[pos] = 0; plane_state[pos] = 0;          // a new scan has no prior and no cached planes
 }
 
 // Work-proportional wave assignment.  The sorted scan is cut into chunks of 64 points; a chunk
