@@ -72,6 +72,7 @@ struct s2m_context {
     std::vector<hipEvent_t> iter_events;
     bool use_graph = true;
     bool fuse_solve = true;            // env S2M_NO_FUSE=1 keeps one k_finalize per iteration (A/B measurements)
+    int  fuse_max_blocks = 0;          // largest grid that closes iterations inside k_register (env S2M_FUSE_MAX overrides)
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
     float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
     int base_parts = 1;
@@ -330,7 +331,8 @@ int push_state(s2m_context* h, const float pose[6])
 {
     DevState s;
     fill_state(h, &s, pose);
-    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, h->stream, h->state.as<DevState>(), s);
+    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, h->stream, h->state.as<DevState>(), s,
+                       (const int32_t*)h->n_waves.as<int32_t>());
     S2M_HIP(h, hipGetLastError());
     return S2M_OK;
 }
@@ -349,12 +351,13 @@ constexpr int kFuseMaxBlocks = 512;
 void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* events)
 {
     const int n = h->prm.max_iter;
-    const bool fuse = h->fuse_solve && nblocks <= kFuseMaxBlocks;
+    DevState* st = h->state.as<DevState>();
+    const bool fuse = h->fuse_solve && nblocks <= h->fuse_max_blocks;
     for (int L = 0; L < n; L++) {
         if (events) (void)hipEventRecord(events[2 * L], h->stream);
-        hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, L, (fuse && L >= 2) ? 1 : 0);
+        hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, (fuse && L >= 2) ? 1 : 0);
         if (events) (void)hipEventRecord(events[2 * L + 1], h->stream);
-        if (!fuse || L == 0 || L == n - 1) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, L, 0);
+        if (!fuse || L == 0 || L == n - 1) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
     }
 }
 
@@ -474,6 +477,8 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->prm = prm; h->device = prm.device_id;
     if (const char* e = getenv("S2M_NO_GRAPH")) h->use_graph = !(e[0] == '1');
     if (const char* e = getenv("S2M_NO_FUSE")) h->fuse_solve = !(e[0] == '1');
+    h->fuse_max_blocks = kFuseMaxBlocks;
+    if (const char* e = getenv("S2M_FUSE_MAX")) h->fuse_max_blocks = atoi(e);
 
     auto bail = [&](int code) { s2m_destroy(h); return code; };
     if (prm.stream) { h->stream = static_cast<hipStream_t>(prm.stream); h->own_stream = false; }
@@ -657,7 +662,7 @@ int s2m_surf_optimization(s2m_handle h, const float pose[6], int32_t* idx5, floa
     h->ctx_dirty = true;
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
-    hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), 0, 0);
+    hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
     S2M_HIP(h, hipGetLastError());
     if (idx5) S2M_HIP(h, hipMemcpyAsync(idx5, h->dbg_idx5.p, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, h->stream));
     if (d2_5) S2M_HIP(h, hipMemcpyAsync(d2_5, h->dbg_d2.p, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, h->stream));
@@ -683,7 +688,7 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
     for (int rep = 0; rep < launches; rep++)
-        hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), 0, 0);
+        hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
     S2M_HIP(h, hipGetLastError());
     const size_t n = nwaves < cap_waves ? nwaves : cap_waves;
     S2M_HIP(h, hipMemcpyAsync(out, h->dbg_clk.p, sizeof(uint64_t) * 16 * n, hipMemcpyDeviceToHost, h->stream));
@@ -709,8 +714,8 @@ int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6]
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
     const DevCtx* dc = h->dctx.as<DevCtx>();
-    hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, 0, 0);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, 0, 1);
+    hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, h->state.as<DevState>(), 0, 0);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, h->state.as<DevState>(), 0, 1);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));

@@ -915,16 +915,16 @@ struct LmShared {
 // matAtA / matAtB / laserCloudSelNum of iteration `iter` from the partial sums of launch `iter`
 // (:1182-1239).  Ends with a workgroup barrier; returns laserCloudSelNum.
 template <int NT>
-__device__ __forceinline__ int lm_normal_eq(const DevCtx* __restrict__ cp, int iter, bool writer, LmShared& sh)
+__device__ __forceinline__ int lm_normal_eq(const DevCtx* __restrict__ cp, gptr<DevState> st, int nb_act, int iter,
+                                            bool writer, LmShared& sh)
 {
     constexpr int NG = NT / 32;                         // row groups
-    const auto st = G(cp->state);
     const int t = threadIdx.x, col = t & 31, grp = t >> 5;
     double s = 0.0;
     if (col < kAcc) {
         const int nbk = cp->nblocks;
         const auto P = G((const double*)cp->partials) + (size_t)(iter & 1) * (size_t)nbk * kAcc;
-        const int nb = min(nbk, (*G(cp->n_waves) + (kBlock / 64) - 1) / (kBlock / 64));   // active workgroups
+        const int nb = min(nbk, nb_act);                // active workgroups
         for (int b0 = grp; b0 < nb; b0 += 16 * NG) {    // 16 independent loads in flight per lane
             double v[16];
 #pragma unroll
@@ -965,10 +965,9 @@ __device__ __forceinline__ int lm_normal_eq(const DevCtx* __restrict__ cp, int i
 // (converged with early exit on, or fewer than min_corr correspondences).  kFull adds the
 // iteration-0 degeneracy analysis on wave 1 (needs >= 2 waves).  `writer` records the outcome.
 template <bool kFull>
-__device__ __forceinline__ bool lm_solve_update(const DevCtx* __restrict__ cp, int iter, int n_sel, bool writer,
+__device__ __forceinline__ bool lm_solve_update(const DevCtx* __restrict__ cp, gptr<DevState> st, int iter, int n_sel, bool writer,
                                                 const float (&pose0)[6], int degen0, LmShared& sh, float (&pose_out)[6])
 {
-    const auto st = G(cp->state);
     const auto trace = G(cp->trace);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 
@@ -1068,11 +1067,14 @@ __device__ __forceinline__ bool lm_solve_update(const DevCtx* __restrict__ cp, i
 }
 
 template <bool HOOK>
-__global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict__ cp, int launch, int solve_prev)
+__global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int launch, int solve_prev)
 {
     constexpr int NW = kBlock / 64;
-    const auto st = G((const DevState*)cp->state);
-    if (!HOOK && st->done) return;
+    // The loop state block never moves, so it comes as a kernel argument: `done` and the wave count arrive
+    // with the first round trip, in parallel with the DevCtx block, instead of behind a pointer chase.
+    const auto st = G(state);
+    const int done = st->done, n_waves = st->n_waves;
+    if (!HOOK && done) return;
     unsigned long long tk_start = 0, tk = 0, t_bbox = 0, t_mark = 0, t_stage = 0, t_search = 0;
     if (HOOK) { tk_start = wall_clock64(); tk = tk_start; }
 #define S2M_LAP(acc) do { if (HOOK) { const unsigned long long n__ = wall_clock64(); (acc) += n__ - tk; tk = n__; } } while (0)
@@ -1085,7 +1087,6 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     // wave w of workgroup b takes entry w*gridDim.x + b of the wave table: neighbouring chunks
     // (similar cost: the sort runs from the dense near field to the sparse far field) land on
     // different CUs, which evens out both the work and the L2-miss queues
-    const int n_waves = *G(cp->n_waves);
     const int nb_act = (n_waves + NW - 1) / NW;            // workgroups the wave table needs
     if ((int)blockIdx.x >= nb_act) return;                 // the rest of the (fixed, graph-captured) grid idles
     const int wg = wave * nb_act + (int)blockIdx.x;
@@ -1141,8 +1142,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
 #pragma unroll
             for (int k = 0; k < 6; k++) pose0[k] = st->pose2[(launch - 1) & 1][k];
             const bool writer = blockIdx.x == 0;
-            const int n_sel = lm_normal_eq<kBlock>(cp, launch - 1, writer, sh);
-            const bool ended = lm_solve_update<false>(cp, launch - 1, n_sel, writer, pose0, degen0, sh, pose);
+            const int n_sel = lm_normal_eq<kBlock>(cp, st, nb_act, launch - 1, writer, sh);
+            const bool ended = lm_solve_update<false>(cp, st, launch - 1, n_sel, writer, pose0, degen0, sh, pose);
             __syncthreads();                               // the scratch is the waves' tile area again
             if (ended) return;
         } else {
@@ -1598,26 +1599,31 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
 // lm_solve_update above): iteration 0 with the degeneracy analysis, and the last iteration of a
 // scan.  mode 1 = normal equations only (observation hook).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restrict__ cp, int iter, int mode)
+__global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int iter, int mode)
 {
-    const auto st = G(cp->state);
-    // loop state, fetched up front so that it is in flight together with the partial sums
+    const auto st = G(state);
+    // loop state, fetched up front (the state block is a kernel argument: no pointer chase through DevCtx)
     const int done0 = st->done, degen0 = st->isDegenerate;
+    const int nb_act = (st->n_waves + (kBlock / 64) - 1) / (kBlock / 64);
     float pose0[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) pose0[k] = st->pose2[iter & 1][k];
     if (mode == 0 && done0) return;
     __shared__ LmShared sh;
-    const int n_sel = lm_normal_eq<kFinThreads>(cp, iter, true, sh);
+    const int n_sel = lm_normal_eq<kFinThreads>(cp, st, nb_act, iter, true, sh);
     if (mode == 1) return;
     float pose[6];
-    lm_solve_update<true>(cp, iter, n_sel, true, pose0, degen0, sh, pose);
+    lm_solve_update<true>(cp, st, iter, n_sel, true, pose0, degen0, sh, pose);
 }
 
 // Parameter blocks travel as kernel arguments (copied at launch), so the host never has to
 // keep a staging buffer alive or synchronise to update them.
 __global__ void k_set_ctx(DevCtx* dst, DevCtx v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
-__global__ void k_set_state(DevState* dst, DevState v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
+// The wave count of the resident scan (left by k_chunk_table) is folded into the state block here.
+__global__ void k_set_state(DevState* dst, DevState v, const int32_t* n_waves)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { v.n_waves = n_waves ? *n_waves : 0; *dst = v; }
+}
 
 // ------------------------------------------------------------------------------------------
 // ScanContext descriptor (include/Scancontext.cpp:151-211): max-z polar histogram, 20 rings x

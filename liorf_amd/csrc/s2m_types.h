@@ -38,6 +38,7 @@ struct DevState {
     int32_t iters_run;
     int32_t n_sel_last;
     int32_t stalled;      // n_sel < min_corr: every further iteration is the same no-op
+    int32_t n_waves;      // wave-table entries of the resident scan (copied in by k_set_state)
     int32_t T_valid;      // 1: T/sc were set by the host (launch 0); 0: k_register rebuilds them from pose2
 };
 
