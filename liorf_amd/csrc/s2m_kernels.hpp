@@ -787,69 +787,63 @@ __device__ __forceinline__ void store_trace(gptr<s2m_iter_trace> dst, const s2m_
 }
 
 // cv::solve(matAtA, matAtB, matX, DECOMP_QR) (:1240) spread over 7 lanes of one wave: lane j < 6
-// owns column j of AtA, lane 6 the right-hand side.  Per reflector l: lane l builds the unit vector
-// (the only serial part: two sqrt, 6-l divides), every owner updates its own column, lane 6
-// applies the stored form of the reflector to b.  Each number goes through exactly the
-// operations, in the order, of OpenCV's hal::QR32f (un-pivoted Householder QR in fp32 with unit-length
-// reflectors, rhs transformed, back substitution; OpenCV >= 3.3).  `sv` is 8 floats of LDS.
-__device__ __forceinline__ bool solve6_qr_lanes(int lane, float (&col)[6], float* sv, float (*sA)[8], float (&x)[6])
+// owns column j of AtA, lane 6 the right-hand side.  Every number goes through exactly the operations,
+// in the order, of OpenCV's hal::QR32f (un-pivoted Householder QR in fp32 with unit-length reflectors,
+// the reflector kept as v/v[0] below the diagonal and re-expanded for the right-hand side, back
+// substitution; OpenCV >= 3.3).  The code is branch-free and LDS-free: all lanes run the reflector
+// arithmetic on their own column, lane l's result is broadcast with v_readlane, and the quotients
+// v[i]/v[0] (needed by lane l for storage and by lane 6 for the rhs) are computed once, wave-uniform.
+// A correctly rounded fp32 divide is ~10 instructions, so the count of divides and the absence of
+// divergent branches decide the latency of this serial chain.  Returns x in every lane.
+__device__ __forceinline__ float lane_bcast(float v, int src_lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
+}
+
+__device__ __forceinline__ bool solve6_qr_lanes(int lane, float (&col)[6], float (&x)[6])
 {
 #pragma unroll
     for (int l = 0; l < 6; l++) {
-        if (lane == l) {
-            float vl[6];
-            float nrm = 0.0f;
+        float vl[6], u[6];
+        // reflector of column l (meaningful in lane l only; the other lanes' values are discarded)
+        float nrm = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 6 - l; i++) { vl[i] = col[l + i]; nrm += vl[i] * vl[i]; }
-            const float tmpV = vl[0];
-            vl[0] = vl[0] + (vl[0] >= 0.0f ? 1.0f : -1.0f) * sqrtf(nrm);
-            nrm = sqrtf(nrm + vl[0] * vl[0] - tmpV * tmpV);
+        for (int i = 0; i < 6 - l; i++) { vl[i] = col[l + i]; nrm += vl[i] * vl[i]; }
+        const float tmpV = vl[0];
+        vl[0] = vl[0] + (vl[0] >= 0.0f ? 1.0f : -1.0f) * sqrtf(nrm);
+        nrm = sqrtf(nrm + vl[0] * vl[0] - tmpV * tmpV);
 #pragma unroll
-            for (int i = 0; i < 6 - l; i++) { vl[i] /= nrm; sv[i] = vl[i]; }
+        for (int i = 0; i < 6 - l; i++) vl[i] = lane_bcast(vl[i] / nrm, l);
+        const float hf = vl[0] * vl[0];
+        u[0] = 1.0f;
+#pragma unroll
+        for (int i = 1; i < 6 - l; i++) u[i] = vl[i] / vl[0];
+        // columns l..5: A -= 2 v (v^T A); rhs: the same reflector rebuilt from its stored form
+        float va = 0.0f, vb = 0.0f;
+#pragma unroll
+        for (int i = l; i < 6; i++) { va += vl[i - l] * col[i]; vb += u[i - l] * col[i]; }
+        const bool is_col = lane >= l && lane < 6, is_rhs = lane == 6;
+#pragma unroll
+        for (int i = l; i < 6; i++) {
+            const float ca = col[i] - 2.0f * vl[i - l] * va;
+            const float cb = col[i] - 2.0f * u[i - l] * vb * hf;
+            col[i] = is_col ? ca : (is_rhs ? cb : col[i]);
         }
-        wave_lds_sync();
-        float vl[6];
 #pragma unroll
-        for (int i = 0; i < 6 - l; i++) vl[i] = sv[i];
-        if (lane >= l && lane < 6) {
-            float v = 0.0f;
-#pragma unroll
-            for (int i = l; i < 6; i++) v += vl[i - l] * col[i];
-#pragma unroll
-            for (int i = l; i < 6; i++) col[i] -= 2.0f * vl[i - l] * v;
-            if (lane == l) {
-#pragma unroll
-                for (int i = 1; i < 6 - l; i++) col[l + i] = vl[i] / vl[0];
-            }
-        } else if (lane == 6) {
-            const float hf = vl[0] * vl[0];
-            float u[6];
-            u[0] = 1.0f;
-#pragma unroll
-            for (int i = 1; i < 6 - l; i++) u[i] = vl[i] / vl[0];
-            float v = 0.0f;
-#pragma unroll
-            for (int i = l; i < 6; i++) v += u[i - l] * col[i];
-#pragma unroll
-            for (int i = l; i < 6; i++) col[i] -= 2.0f * u[i - l] * v * hf;
-        }
-        wave_lds_sync();
+        for (int i = 1; i < 6 - l; i++) col[l + i] = (lane == l) ? u[i] : col[l + i];
     }
-    if (lane < 7) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) sA[i][lane] = col[i];
-    }
-    wave_lds_sync();
+    // back substitution on wave-uniform values: R[i][j] = column j's entry i, b = lane 6's column
     bool ok = true;
     float b[6];
 #pragma unroll
-    for (int i = 0; i < 6; i++) b[i] = sA[i][6];
+    for (int i = 0; i < 6; i++) b[i] = lane_bcast(col[i], 6);
 #pragma unroll
     for (int i = 5; i >= 0; i--) {
 #pragma unroll
-        for (int j = 5; j > i; j--) b[i] -= b[j] * sA[i][j];
-        if (fabsf(sA[i][i]) < FLT_EPSILON * 10.0f) ok = false;
-        b[i] /= sA[i][i];
+        for (int j = 5; j > i; j--) b[i] -= b[j] * lane_bcast(col[i], j);
+        const float d = lane_bcast(col[i], i);
+        if (fabsf(d) < FLT_EPSILON * 10.0f) ok = false;
+        b[i] /= d;
     }
 #pragma unroll
     for (int i = 0; i < 6; i++) x[i] = ok ? b[i] : 0.0f;
@@ -906,20 +900,27 @@ __device__ bool all_eigen_above(const float* A, float thresh)
 struct LmShared {
     double part[kFinThreads / 32][32];
     double tot[32];
-    float  AtA[36], AtB[6], A[6][8], v[8], X[8], pose[8];
-    int    ended;
+    float  AtA[36], AtB[6];
     float  eA[6][6], eV[6][6], eVi[6][6], eV2[6][6], eW[6];      // iteration-0 analysis only
     int    eR[6], eC[6];
 };
 
-// matAtA / matAtB / laserCloudSelNum of iteration `iter` from the partial sums of launch `iter`
-// (:1182-1239).  Ends with a workgroup barrier; returns laserCloudSelNum.
-template <int NT>
-__device__ __forceinline__ int lm_normal_eq(const DevCtx* __restrict__ cp, gptr<DevState> st, int nb_act, int iter,
-                                            bool writer, LmShared& sh)
+// Closes iteration `iter`: matAtA / matAtB / laserCloudSelNum from the partial sums of launch `iter`
+// (:1182-1239), then solve, project, update, test (:1177-1180, :1240-1292).  `pose0` is the pose launch
+// `iter` ran with, `nb_act` the number of workgroups that wrote partial sums.  All NT threads of the
+// workgroup call it; after the first barrier wave 0 works alone (wave-level LDS ordering only) and
+// publishes {pose[6], ended} in `s_out` (8 floats of LDS that outlive `sh`); all threads return the
+// updated pose in pose_out and whether the loop has ended (converged with early exit on, or fewer
+// than min_corr correspondences).  kFull adds the iteration-0 degeneracy analysis on wave 1.
+// `writer` records the outcome in DevState / trace.  ne_only = normal equations only (observation hook).
+template <int NT, bool kFull>
+__device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp, gptr<DevState> st, int nb_act, int iter,
+                                                   bool writer, bool ne_only, const float (&pose0)[6], int degen0,
+                                                   LmShared& sh, float* s_out, float (&pose_out)[6])
 {
     constexpr int NG = NT / 32;                         // row groups
-    const int t = threadIdx.x, col = t & 31, grp = t >> 5;
+    const auto trace = G(cp->trace);
+    const int t = threadIdx.x, col = t & 31, grp = t >> 5, lane = t & 63, wave = t >> 6;
     double s = 0.0;
     if (col < kAcc) {
         const int nbk = cp->nblocks;
@@ -935,135 +936,125 @@ __device__ __forceinline__ int lm_normal_eq(const DevCtx* __restrict__ cp, gptr<
     }
     sh.part[grp][col] = s;
     __syncthreads();
-    if (t < kAcc) {
-        double v = 0.0;
-#pragma unroll
-        for (int g2 = 0; g2 < NG; g2++) v += sh.part[g2][t];
-        sh.tot[t] = v;
-    }
-    __syncthreads();
-    // fp32 matrices (:1184-1186): entry (a, b), a <= b, is sum number a*6 - a(a-1)/2 + (b-a)
-    const int n_sel = (int)sh.tot[27];
-    if (t < 36) {
-        const int a = min(t / 6, t % 6), b = max(t / 6, t % 6);
-        const float v = (float)sh.tot[a * 6 - (a * (a - 1)) / 2 + (b - a)];
-        sh.AtA[t] = v;
-        if (writer) st->AtA[t] = v;
-    } else if (t < 42) {
-        const float v = (float)sh.tot[21 + (t - 36)];
-        sh.AtB[t - 36] = v;
-        if (writer) st->AtB[t - 36] = v;
-    }
-    if (writer && t == 0) st->n_sel_last = n_sel;
-    __syncthreads();
-    return n_sel;
-}
 
-// Solve, project, update, test (:1177-1180, :1240-1292) for iteration `iter` whose normal
-// equations are in `sh`.  `pose0` is the pose launch `iter` ran with.  All threads of the
-// workgroup call it; all return the updated pose in pose_out and whether the loop has ended
-// (converged with early exit on, or fewer than min_corr correspondences).  kFull adds the
-// iteration-0 degeneracy analysis on wave 1 (needs >= 2 waves).  `writer` records the outcome.
-template <bool kFull>
-__device__ __forceinline__ bool lm_solve_update(const DevCtx* __restrict__ cp, gptr<DevState> st, int iter, int n_sel, bool writer,
-                                                const float (&pose0)[6], int degen0, LmShared& sh, float (&pose_out)[6])
-{
-    const auto trace = G(cp->trace);
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-
-    if (n_sel < cp->min_corr) {                         // :1178-1180: false, pose unchanged
-        if (writer && t == 0) {
-            s2m_iter_trace tr;
-            tr.n_sel = n_sel; tr.stepped = 0; tr.deltaR = 0.0f; tr.deltaT = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 6; k++) { tr.pose[k] = pose0[k]; tr.delta[k] = 0.0f; st->pose[k] = pose0[k]; }
-            st->stalled = 1; st->done = 1;              // the remaining iterations repeat this no-op
-            st->iters_run = cp->max_iter;
-            store_trace(trace + iter, tr);
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) pose_out[k] = pose0[k];
-        return true;
-    }
-
-    // ---- wave 0: the QR solve on 7 lanes.  wave 1 (iteration 0 only): the degeneracy analysis.
+    int n_sel = 0;
     if (wave == 0) {
-        float colv[6];
+        if (t < kAcc) {
+            double v = 0.0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) colv[i] = (lane < 6) ? sh.AtA[i * 6 + lane] : ((lane == 6) ? sh.AtB[i] : 0.0f);
-        float X[6];
-        solve6_qr_lanes(lane, colv, sh.v, sh.A, X);     // :1240
-        if (lane == 6) {
-#pragma unroll
-            for (int k = 0; k < 6; k++) sh.X[k] = X[k];
+            for (int g2 = 0; g2 < NG; g2++) v += sh.part[g2][t];
+            sh.tot[t] = v;
         }
-    } else if (kFull && wave == 1 && lane == 0 && iter == 0) {   // :1242-1264
-        int degenerate = 0;
-        if (!all_eigen_above(sh.AtA, cp->eig_thresh)) {
-            // the full restatement: cv::eigen, the row-zeroing loop, matP = matV.inv() * matV2
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eA[i][j] = sh.AtA[i * 6 + j];
-            eigen6_sym(sh.eA, sh.eV, sh.eW, sh.eR, sh.eC);
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eV2[i][j] = sh.eV[i][j];
-            for (int i = 5; i >= 0; i--) {
-                if (sh.eW[i] < cp->eig_thresh) { for (int j = 0; j < 6; j++) sh.eV2[i][j] = 0.0f; degenerate = 1; }
-                else break;
-            }
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eA[i][j] = sh.eV[i][j];
-            inv6_lu(sh.eA, sh.eVi);
-            for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {      // matP = matV.inv() * matV2
-                double a = 0.0;
-                for (int k = 0; k < 6; k++) a += (double)sh.eVi[i][k] * (double)sh.eV2[k][j];
-                st->matP[i * 6 + j] = (float)a;
-            }
+        wave_lds_sync();
+        // fp32 matrices (:1184-1186): entry (a, b), a <= b, is sum number a*6 - a(a-1)/2 + (b-a)
+        n_sel = (int)sh.tot[27];
+        if (t < 36) {
+            const int a = min(t / 6, t % 6), b = max(t / 6, t % 6);
+            const float v = (float)sh.tot[a * 6 - (a * (a - 1)) / 2 + (b - a)];
+            sh.AtA[t] = v;
+            if (writer) st->AtA[t] = v;
+        } else if (t < 42) {
+            const float v = (float)sh.tot[21 + (t - 36)];
+            sh.AtB[t - 36] = v;
+            if (writer) st->AtB[t - 36] = v;
         }
-        // not degenerate: matP is never read before the next scan's iteration 0 rewrites it
-        st->isDegenerate = degenerate;
-        __threadfence_block();
+        if (writer && t == 0) st->n_sel_last = n_sel;
+        wave_lds_sync();
     }
-    __syncthreads();
+    if (ne_only) return false;
 
-    // ---- thread 0: projection, pose update, convergence test (:1266-1292)
-    if (t == 0) {
-        float X[6], pose[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) { X[k] = sh.X[k]; pose[k] = pose0[k]; }
-        if ((kFull && iter == 0) ? (st->isDegenerate != 0) : (degen0 != 0)) {   // :1266-1271 (iteration 0: just decided by wave 1)
-            float X2[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) X2[k] = X[k];
-            for (int i = 0; i < 6; i++) {
-                double a = 0.0;
-                for (int k = 0; k < 6; k++) a += (double)st->matP[i * 6 + k] * (double)X2[k];
-                X[i] = (float)a;
+    if (kFull && iter == 0) {                           // :1242-1264, wave 1 lane 0
+        __syncthreads();
+        if (wave == 1 && lane == 0 && (int)sh.tot[27] >= cp->min_corr) {
+            int degenerate = 0;
+            if (!all_eigen_above(sh.AtA, cp->eig_thresh)) {
+                // the full restatement: cv::eigen, the row-zeroing loop, matP = matV.inv() * matV2
+                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eA[i][j] = sh.AtA[i * 6 + j];
+                eigen6_sym(sh.eA, sh.eV, sh.eW, sh.eR, sh.eC);
+                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eV2[i][j] = sh.eV[i][j];
+                for (int i = 5; i >= 0; i--) {
+                    if (sh.eW[i] < cp->eig_thresh) { for (int j = 0; j < 6; j++) sh.eV2[i][j] = 0.0f; degenerate = 1; }
+                    else break;
+                }
+                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) sh.eA[i][j] = sh.eV[i][j];
+                inv6_lu(sh.eA, sh.eVi);
+                for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) {      // matP = matV.inv() * matV2
+                    double a = 0.0;
+                    for (int k = 0; k < 6; k++) a += (double)sh.eVi[i][k] * (double)sh.eV2[k][j];
+                    st->matP[i * 6 + j] = (float)a;
+                }
             }
+            // not degenerate: matP is never read before the next scan's iteration 0 rewrites it
+            st->isDegenerate = degenerate;
+            __threadfence_block();
         }
+        __syncthreads();                                // thread 0 reads what wave 1 decided
+    }
+
+    if (wave == 0) {
+        if (n_sel < cp->min_corr) {                     // :1178-1180: false, pose unchanged
+            if (t == 0) {
+                if (writer) {
+                    s2m_iter_trace tr;
+                    tr.n_sel = n_sel; tr.stepped = 0; tr.deltaR = 0.0f; tr.deltaT = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 6; k++) { pose[k] += X[k]; sh.pose[k] = pose[k]; }  // :1273-1278
-        const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
-        const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);          // :1280-1283
-        const double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
-        const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);          // :1284-1287
-        const bool conv = ((double)deltaR < cp->conv_deg) && ((double)deltaT < cp->conv_cm);   // :1289
-        sh.ended = (conv && cp->early_exit) ? 1 : 0;                            // break (:1313-1314)
-        if (writer) {
-            s2m_iter_trace tr;
-            tr.n_sel = n_sel; tr.stepped = 1; tr.deltaR = deltaR; tr.deltaT = deltaT;
+                    for (int k = 0; k < 6; k++) { tr.pose[k] = pose0[k]; tr.delta[k] = 0.0f; st->pose[k] = pose0[k]; }
+                    st->stalled = 1; st->done = 1;      // the remaining iterations repeat this no-op
+                    st->iters_run = cp->max_iter;
+                    store_trace(trace + iter, tr);
+                }
 #pragma unroll
-            for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; }
-            // launch iter+1 rebuilds its transform from this pose (k_register prologue)
+                for (int k = 0; k < 6; k++) s_out[k] = pose0[k];
+                s_out[6] = 1.0f;
+            }
+        } else {
+            float colv[6], X[6];
 #pragma unroll
-            for (int k = 0; k < 6; k++) { st->pose[k] = pose[k]; st->pose2[(iter + 1) & 1][k] = pose[k]; }
-            st->T_valid = 0;
-            store_trace(trace + iter, tr);
-            st->iters_run = iter + 1;
-            if (conv && !st->converged) st->converged = 1;
-            if (conv && cp->early_exit) st->done = 1;
+            for (int i = 0; i < 6; i++) colv[i] = (lane < 6) ? sh.AtA[i * 6 + lane] : ((lane == 6) ? sh.AtB[i] : 0.0f);
+            solve6_qr_lanes(lane, colv, X);             // :1240, result in every lane
+            if (t == 0) {                               // projection, pose update, convergence test (:1266-1292)
+                float pose[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) pose[k] = pose0[k];
+                if ((kFull && iter == 0) ? (st->isDegenerate != 0) : (degen0 != 0)) {   // :1266-1271 (iteration 0: just decided by wave 1)
+                    float X2[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) X2[k] = X[k];
+                    for (int i = 0; i < 6; i++) {
+                        double a = 0.0;
+                        for (int k = 0; k < 6; k++) a += (double)st->matP[i * 6 + k] * (double)X2[k];
+                        X[i] = (float)a;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 6; k++) { pose[k] += X[k]; s_out[k] = pose[k]; }        // :1273-1278
+                const double r0 = (double)(X[0] * 57.29578f), r1 = (double)(X[1] * 57.29578f), r2 = (double)(X[2] * 57.29578f);
+                const float deltaR = (float)sqrt(r0 * r0 + r1 * r1 + r2 * r2);          // :1280-1283
+                const double t0 = (double)(X[3] * 100), t1 = (double)(X[4] * 100), t2 = (double)(X[5] * 100);
+                const float deltaT = (float)sqrt(t0 * t0 + t1 * t1 + t2 * t2);          // :1284-1287
+                const bool conv = ((double)deltaR < cp->conv_deg) && ((double)deltaT < cp->conv_cm);   // :1289
+                s_out[6] = (conv && cp->early_exit) ? 1.0f : 0.0f;                      // break (:1313-1314)
+                if (writer) {
+                    s2m_iter_trace tr;
+                    tr.n_sel = n_sel; tr.stepped = 1; tr.deltaR = deltaR; tr.deltaT = deltaT;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { tr.delta[k] = X[k]; tr.pose[k] = pose[k]; }
+                    // launch iter+1 rebuilds its transform from this pose (k_register prologue)
+#pragma unroll
+                    for (int k = 0; k < 6; k++) { st->pose[k] = pose[k]; st->pose2[(iter + 1) & 1][k] = pose[k]; }
+                    st->T_valid = 0;
+                    store_trace(trace + iter, tr);
+                    st->iters_run = iter + 1;
+                    if (conv && !st->converged) st->converged = 1;
+                    if (conv && cp->early_exit) st->done = 1;
+                }
+            }
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 6; k++) pose_out[k] = sh.pose[k];
-    return sh.ended != 0;
+    for (int k = 0; k < 6; k++) pose_out[k] = s_out[k];
+    return s_out[6] != 0.0f;
 }
 
 template <bool HOOK>
@@ -1082,6 +1073,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     __shared__ v4f     s_pts[NW][kTilePts];          // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
     static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
     __shared__ double  red[NW][32];
+    __shared__ float   s_lm_out[8];                  // pose + loop-ended flag published by lm_close_iteration
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // wave w of workgroup b takes entry w*gridDim.x + b of the wave table: neighbouring chunks
@@ -1141,10 +1133,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
             float pose0[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) pose0[k] = st->pose2[(launch - 1) & 1][k];
-            const bool writer = blockIdx.x == 0;
-            const int n_sel = lm_normal_eq<kBlock>(cp, st, nb_act, launch - 1, writer, sh);
-            const bool ended = lm_solve_update<false>(cp, st, launch - 1, n_sel, writer, pose0, degen0, sh, pose);
-            __syncthreads();                               // the scratch is the waves' tile area again
+            const bool ended = lm_close_iteration<kBlock, false>(cp, st, nb_act, launch - 1, blockIdx.x == 0, false, pose0, degen0,
+                                                                 sh, s_lm_out, pose);
             if (ended) return;
         } else {
 #pragma unroll
@@ -1595,9 +1585,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
-// k_finalize: one workgroup closing iteration `iter` on its own (see lm_normal_eq /
-// lm_solve_update above): iteration 0 with the degeneracy analysis, and the last iteration of a
-// scan.  mode 1 = normal equations only (observation hook).
+// k_finalize: one workgroup closing iteration `iter` on its own (lm_close_iteration above):
+// iteration 0 with the degeneracy analysis, and the last iteration of a scan (or every iteration
+// when the grid is too large for the fused form).  mode 1 = normal equations only (observation hook).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int iter, int mode)
 {
@@ -1610,10 +1600,9 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
     for (int k = 0; k < 6; k++) pose0[k] = st->pose2[iter & 1][k];
     if (mode == 0 && done0) return;
     __shared__ LmShared sh;
-    const int n_sel = lm_normal_eq<kFinThreads>(cp, st, nb_act, iter, true, sh);
-    if (mode == 1) return;
+    __shared__ float s_out[8];
     float pose[6];
-    lm_solve_update<true>(cp, st, iter, n_sel, true, pose0, degen0, sh, pose);
+    lm_close_iteration<kFinThreads, true>(cp, st, nb_act, iter, true, mode == 1, pose0, degen0, sh, s_out, pose);
 }
 
 // Parameter blocks travel as kernel arguments (copied at launch), so the host never has to
