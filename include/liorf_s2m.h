@@ -173,11 +173,16 @@ int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, floa
  * and cost more than the steady state. */
 int  s2m_time_iterations(s2m_handle h, const float pose[6], int reps, float* ms_per_iter, int cap);
 
-/* Diagnostics: `launches` k_register passes at `pose` (the last one is recorded; 1 = the pass that
- * inherits its prior from whatever ran before, 3 = steady state at this pose); per wave (64 locality-sorted scan points) 16 words:
- * wall-clock (100 MHz) at start / after the search / after plane+Jacobian / at end; search path
- * (1 LDS tile, 2 gather), box rows, points visited, 0; ticks spent in prior+box / row marking /
- * (unused) / staging / search; 3 spare. Returns the number of waves written (<= cap_waves). */
+/* Diagnostics: `launches` > 0: that many k_register passes at `pose`, the last one recorded (1 = the pass
+ * that inherits its prior from whatever ran before, 3 = steady state at this pose). `launches` < 0: a real LM
+ * loop from `pose` (-launches >= 2) whose launch number -launches is recorded, including the fused close of
+ * the iteration before it. Per wave (up to 64 locality-sorted scan points) S2M_PROF_WORDS words:
+ * [0..3] wall clock (100 MHz) at start / after the search / after plane+Jacobian / at end; [4] search path
+ * (1 LDS tile, 2 gather), [5] box rows, [6] points visited, [7] raw points; [8..12] ticks spent in
+ * prior+box / row marking, points in the wave, staging, search; [13..15] path details; [16..22] wall clock
+ * of the fused LM close: entry, partial sums reduced, normal equations, QR solved, update done, barrier
+ * passed, transform built (0 when the launch closes nothing). Returns the number of waves written. */
+#define S2M_PROF_WORDS 24
 int  s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint64_t* out, size_t cap_waves);
 
 /* ---- The voxel-grid stages either side of the path ----------

@@ -676,22 +676,30 @@ int s2m_surf_optimization(s2m_handle h, const float pose[6], int32_t* idx5, floa
 
 int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint64_t* out, size_t cap_waves)
 {
-    if (!h || !pose || !out || launches < 1) return S2M_ERR_INVALID_ARG;
+    if (!h || !pose || !out || launches == 0) return S2M_ERR_INVALID_ARG;
     if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
     S2M_HIP(h, hipSetDevice(h->device));
     const size_t nwaves = (size_t)h->hctx.nblocks * (kBlock / 64);   // kWaveQ points each
     int rc;
-    if ((rc = ensure(h, h->dbg_clk, sizeof(uint64_t) * 16 * nwaves))) return rc;
-    S2M_HIP(h, hipMemsetAsync(h->dbg_clk.p, 0, sizeof(uint64_t) * 16 * nwaves, h->stream));
+    if ((rc = ensure(h, h->dbg_clk, sizeof(uint64_t) * kProfWords * nwaves))) return rc;
+    S2M_HIP(h, hipMemsetAsync(h->dbg_clk.p, 0, sizeof(uint64_t) * kProfWords * nwaves, h->stream));
     h->hctx.dbg_clk = h->dbg_clk.as<unsigned long long>();
     h->ctx_dirty = true;
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
+    if (launches < 0) {            // a real loop: R0 F0 R1 R2' ... and the recorded launch is number -launches, closing the one before it
+        const DevCtx* dc = h->dctx.as<DevCtx>(); DevState* st = h->state.as<DevState>();
+        hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, st, 0, 0);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, 0, 0);
+        for (int L = 1; L < -launches; L++)
+            hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, st, L, L >= 2 ? 1 : 0);
+        hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, st, -launches, 1);
+    }
     for (int rep = 0; rep < launches; rep++)
         hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
     S2M_HIP(h, hipGetLastError());
     const size_t n = nwaves < cap_waves ? nwaves : cap_waves;
-    S2M_HIP(h, hipMemcpyAsync(out, h->dbg_clk.p, sizeof(uint64_t) * 16 * n, hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipMemcpyAsync(out, h->dbg_clk.p, sizeof(uint64_t) * kProfWords * n, hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
     h->hctx.dbg_clk = nullptr;
     h->ctx_dirty = true;

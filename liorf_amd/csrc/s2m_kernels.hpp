@@ -916,7 +916,8 @@ struct LmShared {
 template <int NT, bool kFull>
 __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp, gptr<DevState> st, int nb_act, int iter,
                                                    bool writer, bool ne_only, const float (&pose0)[6], int degen0,
-                                                   LmShared& sh, float* s_out, float (&pose_out)[6])
+                                                   LmShared& sh, float* s_out, float (&pose_out)[6],
+                                                   unsigned long long* stamps = nullptr)     // diagnostics: 5 wall-clock stamps
 {
     constexpr int NG = NT / 32;                         // row groups
     const auto trace = G(cp->trace);
@@ -936,6 +937,7 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
     }
     sh.part[grp][col] = s;
     __syncthreads();
+    if (stamps) stamps[0] = wall_clock64();
 
     int n_sel = 0;
     if (wave == 0) {
@@ -961,6 +963,7 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
         if (writer && t == 0) st->n_sel_last = n_sel;
         wave_lds_sync();
     }
+    if (stamps) stamps[1] = wall_clock64();
     if (ne_only) return false;
 
     if (kFull && iter == 0) {                           // :1242-1264, wave 1 lane 0
@@ -1012,6 +1015,7 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
 #pragma unroll
             for (int i = 0; i < 6; i++) colv[i] = (lane < 6) ? sh.AtA[i * 6 + lane] : ((lane == 6) ? sh.AtB[i] : 0.0f);
             solve6_qr_lanes(lane, colv, X);             // :1240, result in every lane
+            if (stamps) stamps[2] = wall_clock64();
             if (t == 0) {                               // projection, pose update, convergence test (:1266-1292)
                 float pose[6];
 #pragma unroll
@@ -1051,7 +1055,9 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
             }
         }
     }
+    if (stamps) stamps[3] = wall_clock64();
     __syncthreads();
+    if (stamps) stamps[4] = wall_clock64();
 #pragma unroll
     for (int k = 0; k < 6; k++) pose_out[k] = s_out[k];
     return s_out[6] != 0.0f;
@@ -1067,6 +1073,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     const int done = st->done, n_waves = st->n_waves;
     if (!HOOK && done) return;
     unsigned long long tk_start = 0, tk = 0, t_bbox = 0, t_mark = 0, t_stage = 0, t_search = 0;
+    unsigned long long lm_stamps[7] = { 0, 0, 0, 0, 0, 0, 0 };   // diagnostics of the fused LM close
     if (HOOK) { tk_start = wall_clock64(); tk = tk_start; }
 #define S2M_LAP(acc) do { if (HOOK) { const unsigned long long n__ = wall_clock64(); (acc) += n__ - tk; tk = n__; } } while (0)
 
@@ -1133,8 +1140,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
             float pose0[6];
 #pragma unroll
             for (int k = 0; k < 6; k++) pose0[k] = st->pose2[(launch - 1) & 1][k];
+            if (HOOK) lm_stamps[5] = wall_clock64();
             const bool ended = lm_close_iteration<kBlock, false>(cp, st, nb_act, launch - 1, blockIdx.x == 0, false, pose0, degen0,
-                                                                 sh, s_lm_out, pose);
+                                                                 sh, s_lm_out, pose, HOOK ? lm_stamps : nullptr);
             if (ended) return;
         } else {
 #pragma unroll
@@ -1154,6 +1162,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
         sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
     }
 
+    if (HOOK) lm_stamps[6] = wall_clock64();
     Top5 best;
 #pragma unroll
     for (int k = 0; k < 5; k++) { best.key[k] = kKeyInf; best.x[k] = 0.0f; best.y[k] = 0.0f; best.z[k] = 0.0f; }
@@ -1569,10 +1578,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     acc[0] += __shfl_xor(acc[0], 1, 64);
     if ((lane & 1) == 0) red[wave][lane >> 1] = acc[0];
     if (HOOK && cp->dbg_clk && lane == 0) {
-        const auto d = G(cp->dbg_clk) + 16 * ((size_t)blockIdx.x * NW + wave);
+        const auto d = G(cp->dbg_clk) + kProfWords * ((size_t)blockIdx.x * NW + wave);
         d[0] = tk_start; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
         d[4] = (unsigned long long)dbg_mode; d[5] = (unsigned long long)dbg_rows; d[6] = (unsigned long long)dbg_pts; d[7] = (unsigned long long)dbg_raw;
         d[8] = t_bbox; d[9] = t_mark; d[10] = (unsigned long long)chunk.y; d[11] = t_stage; d[12] = t_search; d[13] = (unsigned long long)dbg_why; d[14] = (unsigned long long)dbg_box; d[15] = (unsigned long long)dbg_skip;
+        // fused LM close (solve_prev launches): entry, partial sums reduced, normal equations, QR, update, barrier, T built
+        d[16] = lm_stamps[5]; d[17] = lm_stamps[0]; d[18] = lm_stamps[1]; d[19] = lm_stamps[2]; d[20] = lm_stamps[3]; d[21] = lm_stamps[4]; d[22] = lm_stamps[6]; d[23] = 0;
     }
     __syncthreads();
     if (tid < kAcc) {

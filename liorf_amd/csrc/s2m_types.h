@@ -11,6 +11,7 @@ constexpr int kBlock = 512;            // threads per workgroup of the registrat
 constexpr int kAcc = 28;               // 21 upper-triangular JtJ + 6 Jtr + 1 correspondence count
 constexpr int kFinThreads = 1024;      // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
+constexpr int kProfWords = 24;         // uint64 words per wave written by the diagnostics variant of k_register
 constexpr int kBlocksQuantum = 8;      // graph cache key granularity (workgroups)
 
 // Uniform search grid over the map: cell edge E >= sqrt(gate_sq)*(1+2^-10), so the 3x3x3
@@ -68,7 +69,7 @@ struct DevCtx {
     int32_t ablate;               // diagnostics only (env S2M_ABLATE): 1 skip search, 2 skip plane/Jacobian, 4 skip reduction, 8 skip staging, 16 ignore the prior, 32 ignore the plane cache, 64 gather path only
     // observation outputs of the hook variant (original scan order), may be null
     int32_t* dbg_idx5; float* dbg_d2; uint8_t* dbg_flag; float* dbg_coeff;
-    unsigned long long* dbg_clk;  // [nwaves][8] per-wave wall-clock stamps + tile stats (diagnostics)
+    unsigned long long* dbg_clk;  // [nwaves][kProfWords] per-wave wall-clock stamps + tile stats (diagnostics)
 };
 
 }  // namespace s2m
