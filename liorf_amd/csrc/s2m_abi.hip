@@ -298,8 +298,8 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
         if ((rc = ensure(h, h->chunk_parts, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
         if ((rc = ensure(h, h->wave_table, sizeof(int2) * (size_t)capacity))) return rc;
         if ((rc = ensure(h, h->n_waves, 64))) return rc;
-        hipLaunchKernelGGL(k_chunk_parts, dim3((n_chunks + 3) / 4), dim3(256), 0, h->stream, (const float*)h->qx.as<float>(),
-                           (const float*)h->qy.as<float>(), (const float*)h->qz.as<float>(), (int)n, n_chunks, h->base_parts, h->chunk_parts.as<int32_t>());
+        hipLaunchKernelGGL(k_chunk_parts, dim3((n_chunks + 3) / 4), dim3(256), 0, h->stream, h->qx.as<float>(), h->qy.as<float>(),
+                           h->qz.as<float>(), h->qperm.as<int32_t>(), (int)n, n_chunks, h->base_parts, h->chunk_parts.as<int32_t>());
         hipLaunchKernelGGL(k_chunk_table, dim3(1), dim3(1024), 0, h->stream, (const int32_t*)h->chunk_parts.as<int32_t>(), (int)n, n_chunks,
                            capacity, h->wave_table.as<int2>(), h->n_waves.as<int32_t>());
         S2M_HIP(h, hipGetLastError());

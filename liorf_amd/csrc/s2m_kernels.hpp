@@ -306,16 +306,17 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
 // stage and sweep a large map tile, and the slowest wave sets the kernel time.  Such chunks are
 // given to 2, 4 or 8 waves (32 / 16 / 8 points each: tighter boxes, run in parallel).  The extent is
 // measured in the lidar frame - a rigid transform does not change it.
-__global__ __launch_bounds__(256) void k_chunk_parts(const float* __restrict__ qx, const float* __restrict__ qy,
-                                                     const float* __restrict__ qz, int n, int n_chunks, int base_parts,
-                                                     int32_t* __restrict__ parts)
+__global__ __launch_bounds__(256) void k_chunk_parts(float* __restrict__ qx, float* __restrict__ qy,
+                                                     float* __restrict__ qz, int32_t* __restrict__ qperm, int n, int n_chunks,
+                                                     int base_parts, int32_t* __restrict__ parts)
 {
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
     const int i = c * 64 + lane;
     const bool v = i < n;
-    const float x = v ? qx[i] : 0.0f, y = v ? qy[i] : 0.0f, z = v ? qz[i] : 0.0f;
+    float x = v ? qx[i] : 0.0f, y = v ? qy[i] : 0.0f, z = v ? qz[i] : 0.0f;
+    int perm = v ? qperm[i] : 0;
     const bool f = v && fabsf(x) < 3.0e38f && fabsf(y) < 3.0e38f && fabsf(z) < 3.0e38f;
     float mn[3] = { f ? x : INFINITY, f ? y : INFINITY, f ? z : INFINITY };
     float mx[3] = { f ? x : -INFINITY, f ? y : -INFINITY, f ? z : -INFINITY };
@@ -326,6 +327,31 @@ __global__ __launch_bounds__(256) void k_chunk_parts(const float* __restrict__ q
             mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64));
             mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64));
         }
+    }
+    // Order inside the chunk: the polar cells ignore height and the rank inside a cell is arbitrary, so
+    // the 64 points of a chunk on a facade are stacked over its full height in no order, and cutting the
+    // chunk into 2..8 waves would leave every part as tall as the whole.  Sort the chunk along its
+    // longest axis (bitonic network over the wave, ties by scan index: deterministic), so that the parts
+    // are compact.  Lanes past the end of the scan and non-finite points sort last.
+    if (mn[0] <= mx[0]) {
+        const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+        float key = (ex >= ey && ex >= ez) ? x : ((ey >= ez) ? y : z);
+        if (!f) key = INFINITY;
+        int ord = v ? perm : 0x7fffffff;
+#pragma unroll
+        for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const float okey = __shfl_xor(key, j, 64);
+                const int oord = __shfl_xor(ord, j, 64), operm = __shfl_xor(perm, j, 64);
+                const float ox = __shfl_xor(x, j, 64), oy = __shfl_xor(y, j, 64), oz = __shfl_xor(z, j, 64);
+                const bool lower = (lane & j) == 0, asc = (lane & k) == 0;
+                const bool mine_first = (key < okey) || (key == okey && ord < oord);     // strict order: (key, ord) pairs are distinct
+                const bool keep = (lower == asc) ? mine_first : !mine_first;
+                if (!keep) { key = okey; ord = oord; perm = operm; x = ox; y = oy; z = oz; }
+            }
+        }
+        if (v) { qx[i] = x; qy[i] = y; qz[i] = z; qperm[i] = perm; }
     }
     if (lane == 0) {
         int p = 1;
