@@ -1106,6 +1106,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     __shared__ v4f     s_pts[NW][kTilePts];          // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
     static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
     __shared__ double  red[NW][32];
+    __shared__ int2    s_rows[NW][64];              // per wave: the non-empty box rows of the current row group
     __shared__ float   s_lm_out[8];                  // pose + loop-ended flag published by lm_close_iteration
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1121,6 +1122,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     const int nq = cp->n_q;
     const bool valid = lane < chunk.y && i < nq;
     v4f* lpts = s_pts[wave];
+    int2* lrows = s_rows[wave];
 
     const GridDesc g = cp->g;
     const auto map = G((const v4f*)cp->map_sorted);
@@ -1297,12 +1299,18 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
             S2M_LAP(t_mark);
             // ---- stage through the filter: 16 lanes per row, 8 rows in flight per pass; a point
             // enters the tile only if it lies inside the wave's point box grown by the largest bound
+            // Rows nobody marked, and marked rows that are empty, are squeezed out first (through LDS): every
+            // batch of 8 rows costs a dependent round trip to the map whatever it holds.
             const int sub = lane >> 4, l16 = lane & 15;
-            const int nr = min(64, R - rg);
+            const unsigned long long nzrows = __ballot(len > 0);
+            const int nr = __popcll(nzrows);
+            if (len > 0) lrows[__popcll(nzrows & ((1ull << lane) - 1ull))] = make_int2(gs, len);
+            wave_lds_sync();
             for (int cb = 0; cb < nr && tile; cb += 8) {
-                const int ca = cb + sub, cc = min(cb + 4 + sub, 63);
-                const int gsa = __shfl(gs, ca, 64), na = __shfl(len, ca, 64);
-                const int gsc = __shfl(gs, cc, 64), nn = (cb + 4 + sub < 64) ? __shfl(len, cc, 64) : 0;
+                const int ca = cb + sub, cc = cb + 4 + sub;
+                int gsa = 0, na = 0, gsc = 0, nn = 0;
+                if (ca < nr) { const int2 rw = lrows[ca]; gsa = rw.x; na = rw.y; }
+                if (cc < nr) { const int2 rw = lrows[cc]; gsc = rw.x; nn = rw.y; }
                 const int npass = wave_max_i32(max(na, nn));
                 for (int k0 = 0; k0 < npass; k0 += 16) {
                     const int k = k0 + l16;
