@@ -46,7 +46,7 @@ struct s2m_context {
     // map side
     DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
     // scan side
-    DevBuf raw_scan, qx, qy, qz, qperm, prevp, prior_valid, plane_cache, plane_state, chunk_parts, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
+    DevBuf raw_scan, qx, qy, qz, qperm, prevp, prior_valid, plane_cache, plane_state, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
     // voxel-grid stages that feed the path (section 8(f) F1/F2): staging for host clouds, transformed key frames, filtered clouds
@@ -76,6 +76,7 @@ struct s2m_context {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
     float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
     int base_parts = 1;
+    int density_raw = 320;             // box points above which a wave asks for a finer cut (env S2M_DENSITY_RAW, 0 = off)
     bool opt_pending = false;
     bool scan_timing_pending = false;
     int pending_skipped = 0;
@@ -296,6 +297,11 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     {
         const int capacity = h->hctx.nblocks * (kBlock / 64);
         if ((rc = ensure(h, h->chunk_parts, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
+        {   // density wishes: all zero between uses (k_chunk_table_density clears what it consumes)
+            const void* before = h->chunk_factor.p;
+            if ((rc = ensure(h, h->chunk_factor, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
+            if (h->chunk_factor.p != before) S2M_HIP(h, hipMemsetAsync(h->chunk_factor.p, 0, h->chunk_factor.cap, h->stream));
+        }
         if ((rc = ensure(h, h->wave_table, sizeof(int2) * (size_t)capacity))) return rc;
         if ((rc = ensure(h, h->n_waves, 64))) return rc;
         hipLaunchKernelGGL(k_chunk_parts, dim3((n_chunks + 3) / 4), dim3(256), 0, h->stream, h->qx.as<float>(), h->qy.as<float>(),
@@ -305,6 +311,11 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
         S2M_HIP(h, hipGetLastError());
         h->hctx.wave_table = h->wave_table.as<int2>();
         h->hctx.n_waves = h->n_waves.as<int32_t>();
+        h->hctx.wave_table_rw = h->wave_table.as<int2>();
+        h->hctx.n_waves_rw = h->n_waves.as<int32_t>();
+        h->hctx.chunk_parts = h->chunk_parts.as<int32_t>();
+        h->hctx.chunk_factor = h->chunk_factor.as<int32_t>();
+        h->hctx.n_chunks = n_chunks;
     }
     h->hctx.prevp = h->prevp.as<float4>();
     h->hctx.prior_valid = h->prior_valid.as<int32_t>();
@@ -353,6 +364,13 @@ void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* eve
     const int n = h->prm.max_iter;
     DevState* st = h->state.as<DevState>();
     const bool fuse = h->fuse_solve && nblocks <= h->fuse_max_blocks;
+    if (h->density_raw > 0) {
+        // re-split the wave table for the map density at the initial guess (the transform k_set_state just stored);
+        // both kernels take everything from the DevCtx block, so the captured graph stays valid from scan to scan
+        hipLaunchKernelGGL(k_wave_density, dim3((nblocks * (kBlock / 64) + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
+                           h->density_raw);
+        hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, dc, st);
+    }
     for (int L = 0; L < n; L++) {
         if (events) (void)hipEventRecord(events[2 * L], h->stream);
         hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, (fuse && L >= 2) ? 1 : 0);
@@ -477,6 +495,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->prm = prm; h->device = prm.device_id;
     if (const char* e = getenv("S2M_NO_GRAPH")) h->use_graph = !(e[0] == '1');
     if (const char* e = getenv("S2M_NO_FUSE")) h->fuse_solve = !(e[0] == '1');
+    if (const char* e = getenv("S2M_DENSITY_RAW")) h->density_raw = atoi(e);
     h->fuse_max_blocks = kFuseMaxBlocks;
     if (const char* e = getenv("S2M_FUSE_MAX")) h->fuse_max_blocks = atoi(e);
 
@@ -527,7 +546,7 @@ int s2m_destroy(s2m_handle h)
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
-                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->prior_valid, &h->plane_cache, &h->plane_state, &h->chunk_parts, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->prior_valid, &h->plane_cache, &h->plane_state, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out,
                        &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds };

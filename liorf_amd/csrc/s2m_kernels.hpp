@@ -329,24 +329,30 @@ __global__ __launch_bounds__(256) void k_chunk_parts(float* __restrict__ qx, flo
         }
     }
     // Order inside the chunk: the polar cells ignore height and the rank inside a cell is arbitrary, so
-    // the 64 points of a chunk on a facade are stacked over its full height in no order, and cutting the
-    // chunk into 2..8 waves would leave every part as tall as the whole.  Sort the chunk along its
-    // longest axis (bitonic network over the wave, ties by scan index: deterministic), so that the parts
-    // are compact.  Lanes past the end of the scan and non-finite points sort last.
+    // the 64 points of a chunk are in no useful order, and cutting the chunk into 2..8 waves would leave
+    // every part as large as the whole.  Sort the chunk along a 3-D Morton curve over its own bounding
+    // box (cubic cells, 16 along the longest axis; bitonic network over the wave, ties by scan index:
+    // deterministic), so that every part is a compact blob whatever the sensor's heading is.  Lanes past
+    // the end of the scan and non-finite points sort last.
     if (mn[0] <= mx[0]) {
-        const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
-        float key = (ex >= ey && ex >= ez) ? x : ((ey >= ez) ? y : z);
-        if (!f) key = INFINITY;
+        const float emax = fmaxf(fmaxf(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+        const float sc = emax > 0.0f ? 15.99f / emax : 0.0f;
+        auto spread4 = [](uint32_t b) { return (b & 1u) | ((b & 2u) << 2) | ((b & 4u) << 4) | ((b & 8u) << 6); };   // bit k -> bit 3k
+        uint32_t key = 0x7fffffffu;
+        if (f) {
+            const uint32_t ix = (uint32_t)((x - mn[0]) * sc), iy = (uint32_t)((y - mn[1]) * sc), iz = (uint32_t)((z - mn[2]) * sc);
+            key = spread4(min(ix, 15u)) | (spread4(min(iy, 15u)) << 1) | (spread4(min(iz, 15u)) << 2);
+        }
         int ord = v ? perm : 0x7fffffff;
 #pragma unroll
         for (int k = 2; k <= 64; k <<= 1) {
 #pragma unroll
             for (int j = k >> 1; j > 0; j >>= 1) {
-                const float okey = __shfl_xor(key, j, 64);
+                const uint32_t okey = (uint32_t)__shfl_xor((int)key, j, 64);
                 const int oord = __shfl_xor(ord, j, 64), operm = __shfl_xor(perm, j, 64);
                 const float ox = __shfl_xor(x, j, 64), oy = __shfl_xor(y, j, 64), oz = __shfl_xor(z, j, 64);
                 const bool lower = (lane & j) == 0, asc = (lane & k) == 0;
-                const bool mine_first = (key < okey) || (key == okey && ord < oord);     // strict order: (key, ord) pairs are distinct
+                const bool mine_first = (key < okey) || (key == okey && ord < oord);     // (key, ord) pairs of real points are distinct
                 const bool keep = (lower == asc) ? mine_first : !mine_first;
                 if (!keep) { key = okey; ord = oord; perm = operm; x = ox; y = oy; z = oz; }
             }
@@ -368,15 +374,19 @@ __global__ __launch_bounds__(256) void k_chunk_parts(float* __restrict__ qx, flo
 // one workgroup: exclusive scan of parts[] and emission of the wave table {first point, count}.
 // The table has room for every chunk unsplit plus a budget of extra waves; if the wishes exceed
 // it they are scaled back uniformly (cap 8 -> 4 -> 2 -> 1), so the table never overflows.
-__global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict__ parts, int n, int n_chunks, int capacity,
-                                                      int2* __restrict__ table, int32_t* __restrict__ n_waves_out)
+// `factor` (optional, consumed and zeroed): extra split asked for by k_wave_density; `st` (optional)
+// receives the new wave count as well.
+__device__ __forceinline__ void chunk_table_body(const int32_t* __restrict__ parts, int n, int n_chunks, int capacity,
+                                                 int2* __restrict__ table, int32_t* __restrict__ n_waves_out,
+                                                 int32_t* __restrict__ factor, DevState* __restrict__ st)
 {
     __shared__ int32_t wsum[16];
     __shared__ int32_t carry_s, tot_s[3];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // pass A: total waves wished for when parts are capped at 8, 4, 2
     int t8 = 0, t4 = 0, t2 = 0;
-    for (int c = threadIdx.x; c < n_chunks; c += 1024) { const int p = parts[c]; t8 += p; t4 += min(p, 4); t2 += min(p, 2); }
+    auto wish = [&](int c) { return min(8, parts[c] * (factor ? max(factor[c], 1) : 1)); };
+    for (int c = threadIdx.x; c < n_chunks; c += 1024) { const int p = wish(c); t8 += p; t4 += min(p, 4); t2 += min(p, 2); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { t8 += __shfl_xor(t8, off, 64); t4 += __shfl_xor(t4, off, 64); t2 += __shfl_xor(t2, off, 64); }
     if (threadIdx.x == 0) { carry_s = 0; tot_s[0] = 0; tot_s[1] = 0; tot_s[2] = 0; }
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict_
     // pass B: scan and emit
     for (int base = 0; base < n_chunks; base += 1024) {
         const int c = base + threadIdx.x;
-        const int p = (c < n_chunks) ? min(parts[c], pcap) : 0;
+        const int p = (c < n_chunks) ? min(wish(c), pcap) : 0;
         int incl = p;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -411,7 +421,26 @@ __global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict_
         if (threadIdx.x == 1023) carry_s = carry + woff + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *n_waves_out = min(carry_s, capacity);
+    if (threadIdx.x == 0) {
+        const int nw = min(carry_s, capacity);
+        *n_waves_out = nw;
+        if (st) st->n_waves = nw;
+    }
+    if (factor) for (int c = threadIdx.x; c < n_chunks; c += 1024) factor[c] = 0;   // every wish above was read before the last barrier
+}
+
+// per s2m_set_scan: extent-based parts only
+__global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict__ parts, int n, int n_chunks, int capacity,
+                                                      int2* __restrict__ table, int32_t* __restrict__ n_waves_out)
+{
+    chunk_table_body(parts, n, n_chunks, capacity, table, n_waves_out, nullptr, nullptr);
+}
+
+// per scan before launch 0, inside the captured loop: everything comes from the DevCtx block
+__global__ __launch_bounds__(1024) void k_chunk_table_density(const DevCtx* __restrict__ cp, DevState* __restrict__ st)
+{
+    chunk_table_body(cp->chunk_parts, cp->n_q, cp->n_chunks, cp->nblocks * (kBlock / 64), cp->wave_table_rw, cp->n_waves_rw,
+                     cp->chunk_factor, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1087,6 +1116,59 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
 #pragma unroll
     for (int k = 0; k < 6; k++) pose_out[k] = s_out[k];
     return s_out[6] != 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// Density-aware re-split of the wave table, once per scan before launch 0.  k_chunk_parts can only
+// look at the extent of a chunk in the lidar frame; how many map points fall into a wave's box is
+// known once the initial guess is.  All workgroups start together, so a launch lasts as long as its
+// slowest wave, and the slowest waves are the few whose box covers a dense part of the map (they
+// stage and sweep a large tile, or overflow it and fall back to the gather path).  One wave per
+// table entry transforms its points with the initial guess and sums the cell ranges of its box rows
+// (what launch 0 will stream); only the heavy tail asks for its chunk to be cut 2, 4 or 8 times
+// finer (the chunk is sorted along its longest axis, so the parts are compact), and
+// k_chunk_table_density rebuilds the table.  Partition only: results do not depend on it beyond the
+// summation order of the normal equations.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_wave_density(const DevCtx* __restrict__ cp, const DevState* __restrict__ state, int raw_limit)
+{
+    const auto st = G(state);
+    const int lane = threadIdx.x & 63;
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= st->n_waves) return;
+    const auto tb = G((const int2*)cp->wave_table);
+    const int2 e = make_int2(tb[wv].x, tb[wv].y);
+    const int i = e.x + lane;
+    const bool valid = lane < e.y && i < cp->n_q;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    if (valid) {
+        const float px = G(cp->qx)[i], py = G(cp->qy)[i], pz = G(cp->qz)[i];
+        sx = ((st->T[0] * px + st->T[1] * py) + st->T[2]  * pz) + st->T[3];
+        sy = ((st->T[4] * px + st->T[5] * py) + st->T[6]  * pz) + st->T[7];
+        sz = ((st->T[8] * px + st->T[9] * py) + st->T[10] * pz) + st->T[11];
+    }
+    const bool fin = valid && (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
+    const float mnx = wave_min_f32(fin ? sx : INFINITY), mxx = wave_max_f32(fin ? sx : -INFINITY);
+    const float mny = wave_min_f32(fin ? sy : INFINITY), mxy = wave_max_f32(fin ? sy : -INFINITY);
+    const float mnz = wave_min_f32(fin ? sz : INFINITY), mxz = wave_max_f32(fin ? sz : -INFINITY);
+    if (!(mnx <= mxx)) return;
+    const GridDesc g = cp->g;
+    const auto cell_start = G(cp->cell_start);
+    const int bx0 = max(cell_coord(mnx, g.ox, g.inv_e, g.nx) - 1, 0), bx1 = min(cell_coord(mxx, g.ox, g.inv_e, g.nx) + 1, g.nx - 1);
+    const int by0 = max(cell_coord(mny, g.oy, g.inv_e, g.ny) - 1, 0), by1 = min(cell_coord(mxy, g.oy, g.inv_e, g.ny) + 1, g.ny - 1);
+    const int bz0 = max(cell_coord(mnz, g.oz, g.inv_e, g.nz) - 1, 0), bz1 = min(cell_coord(mxz, g.oz, g.inv_e, g.nz) + 1, g.nz - 1);
+    const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
+    if (nyb * nzb > kRowMax) return;                      // scattered points: the gather path's business, a finer cut does not help
+    int raw = 0;
+    for (int r = lane; r < nyb * nzb; r += 64) {
+        const int zq = r / nyb;
+        const int gcell = ((bz0 + zq) * g.ny + by0 + (r - zq * nyb)) * g.nx;
+        raw += cell_start[gcell + bx1 + 1] - cell_start[gcell + bx0];
+    }
+    raw = __builtin_amdgcn_readlane(wave_incl_scan_i32(raw), 63);
+    int f = raw <= raw_limit ? 1 : (raw <= 2 * raw_limit ? 2 : (raw <= 4 * raw_limit ? 4 : 8));
+    f = min(f, max(e.y / 8, 1));                          // at least 8 points per wave
+    if (lane == 0 && f > 1) atomicMax(&cp->chunk_factor[e.x >> 6], f);
 }
 
 template <bool HOOK>

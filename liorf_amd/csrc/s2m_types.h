@@ -58,6 +58,11 @@ struct DevCtx {
     int32_t n_q, n_m, nblocks;
     const int2* wave_table;       // [nblocks*4] {first sorted point, count <= 64} per wave
     const int32_t* n_waves;       // entries of wave_table in use
+    // the same table for the kernels that rebuild it before launch 0 (k_wave_density, k_chunk_table_density)
+    int2*    wave_table_rw; int32_t* n_waves_rw;
+    const int32_t* chunk_parts;   // [n_chunks] extent-based split wish per 64-point chunk
+    int32_t* chunk_factor;        // [n_chunks] density-based extra split, zero between uses
+    int32_t  n_chunks;
     double* partials;             // [2][nblocks][kAcc], slot = launch parity
     DevState* state;
     s2m_iter_trace* trace;        // [kMaxIter]
