@@ -1432,21 +1432,49 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
             if (!(ablate & 1)) {
                 const bool prior_ok = fin && best.key[4] != kKeyInf &&
                                       __uint_as_float((uint32_t)(best.key[4] >> 32)) <= bound;
-                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                for (int seg = 0; seg < 2; seg++) {
-                    const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                    int j = jb;
-                    for (; j + 4 <= je; j += 4) {
-                        const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                        float d0, d1, d2v, d3;
-                        make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                        make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                        c0 += (d0 <= bound) ? 1 : 0; c1 += (d1 <= bound) ? 1 : 0;
-                        c2 += (d2v <= bound) ? 1 : 0; c3 += (d3 <= bound) ? 1 : 0;
-                    }
-                    for (; j < je; j++) { float d; make_key(lpts[j], sx, sy, sz, d); c0 += (d <= bound) ? 1 : 0; }
+                // A wave of a split chunk holds 32, 16 or 8 points in its first lanes; the idle lanes join
+                // in: kq = 2, 4 or 8 lanes share a point, each counts every kq-th tile point, and the
+                // partial counts are added across the group.  (These short waves are the ones in dense
+                // parts of the map, i.e. the slowest of a launch.)
+                const int kq = (chunk.y > 32) ? 1 : ((chunk.y > 16) ? 2 : ((chunk.y > 8) ? 4 : 8));
+                const int nslot = 64 / kq, part = lane / nslot;
+                float qx_ = sx, qy_ = sy, qz_ = sz, qb_ = bound;
+                if (kq > 1) {
+                    const int src = lane & (nslot - 1);
+                    qx_ = __shfl(sx, src, 64); qy_ = __shfl(sy, src, 64); qz_ = __shfl(sz, src, 64); qb_ = __shfl(bound, src, 64);
                 }
-                const int cnt = c0 + c1 + c2 + c3;
+                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                if (kq == 1) {                            // the common case, with compile-time LDS offsets
+                    for (int seg = 0; seg < 2; seg++) {
+                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                        int j = jb;
+                        for (; j + 4 <= je; j += 4) {
+                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                            float d0, d1, d2v, d3;
+                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                            c0 += (d0 <= bound) ? 1 : 0; c1 += (d1 <= bound) ? 1 : 0;
+                            c2 += (d2v <= bound) ? 1 : 0; c3 += (d3 <= bound) ? 1 : 0;
+                        }
+                        for (; j < je; j++) { float d; make_key(lpts[j], sx, sy, sz, d); c0 += (d <= bound) ? 1 : 0; }
+                    }
+                } else {
+                    for (int seg = 0; seg < 2; seg++) {
+                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                        int j = jb + part;
+                        for (; j + 3 * kq < je; j += 4 * kq) {
+                            const v4f m0 = lpts[j], m1 = lpts[j + kq], m2 = lpts[j + 2 * kq], m3 = lpts[j + 3 * kq];
+                            float d0, d1, d2v, d3;
+                            make_key(m0, qx_, qy_, qz_, d0); make_key(m1, qx_, qy_, qz_, d1);
+                            make_key(m2, qx_, qy_, qz_, d2v); make_key(m3, qx_, qy_, qz_, d3);
+                            c0 += (d0 <= qb_) ? 1 : 0; c1 += (d1 <= qb_) ? 1 : 0;
+                            c2 += (d2v <= qb_) ? 1 : 0; c3 += (d3 <= qb_) ? 1 : 0;
+                        }
+                        for (; j < je; j += kq) { float d; make_key(lpts[j], qx_, qy_, qz_, d); c0 += (d <= qb_) ? 1 : 0; }
+                    }
+                }
+                int cnt = c0 + c1 + c2 + c3;
+                for (int m = nslot; m < 64; m <<= 1) cnt += __shfl_xor(cnt, m, 64);
                 if (prior_ok && cnt == 5) todo = false;
                 else if (fin && bound >= gatef && cnt < 5) { todo = false; certain_far = true; }
             }
