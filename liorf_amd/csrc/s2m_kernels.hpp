@@ -623,6 +623,7 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // ------------------------------------------------------------------------------------------
 constexpr int kTilePts = 320;        // points per wave tile (5 KiB) after filtering
 constexpr int kTileRaw = 448;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
+constexpr int kCand = 24;            // candidate-list capacity per lane (tile positions, uint16)
 constexpr int kRowMax = 256;         // boxes with more rows go straight to the gather path
 constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning (<= 5e-5)
 constexpr uint64_t kKeyInf = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu;
@@ -1188,6 +1189,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     __shared__ v4f     s_pts[NW][kTilePts];          // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
     static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
     __shared__ double  red[NW][32];
+    __shared__ uint16_t s_cand[NW][kCand * 64];     // per wave: tile positions of each lane's candidates, [k][lane]
     __shared__ int2    s_rows[NW][64];              // per wave: the non-empty box rows of the current row group
     __shared__ float   s_lm_out[8];                  // pose + loop-ended flag published by lm_close_iteration
 
@@ -1205,6 +1207,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     const bool valid = lane < chunk.y && i < nq;
     v4f* lpts = s_pts[wave];
     int2* lrows = s_rows[wave];
+    uint16_t* lcand = s_cand[wave];
 
     const GridDesc g = cp->g;
     const auto map = G((const v4f*)cp->map_sorted);
@@ -1428,7 +1431,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
             //    prior points are in the tile: their rows were marked and they pass the filter), so the
             //    ordered neighbour set is the prior;
             //  - bound is the gate and fewer than 5: the point is not gated, whatever its neighbours are.
-            bool todo = fin;                              // lanes that still need the full sweep
+            bool todo = fin;                              // lanes that still need a sweep
+            float tb = bound;                             // radius (squared) of this lane's candidate list ...
+            int ccnt = 0;                                 // ... and the number of tile points inside it
             if (!(ablate & 1)) {
                 const bool prior_ok = fin && best.key[4] != kKeyInf &&
                                       __uint_as_float((uint32_t)(best.key[4] >> 32)) <= bound;
@@ -1436,7 +1441,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
                 // in: kq = 2, 4 or 8 lanes share a point, each counts every kq-th tile point, and the
                 // partial counts are added across the group.  (These short waves are the ones in dense
                 // parts of the map, i.e. the slowest of a launch.)
-                const int kq = (chunk.y > 32) ? 1 : ((chunk.y > 16) ? 2 : ((chunk.y > 8) ? 4 : 8));
+                // `cold`: some lane has no usable prior (first launch of a scan, or the prior was lost).  Its
+                // bound is the gate, and a candidate list cut at the gate could be long; so the sweep counts
+                // against four radii at once (bound, /2, /4, /8) and each lane keeps the tightest one that
+                // still holds 5 points: tb, with ccnt points inside.
+                const bool cold = __ballot(fin && !prior_ok) != 0ull;
+                const int kq = cold ? 1 : ((chunk.y > 32) ? 1 : ((chunk.y > 16) ? 2 : ((chunk.y > 8) ? 4 : 8)));
                 const int nslot = 64 / kq, part = lane / nslot;
                 float qx_ = sx, qy_ = sy, qz_ = sz, qb_ = bound;
                 if (kq > 1) {
@@ -1444,7 +1454,30 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
                     qx_ = __shfl(sx, src, 64); qy_ = __shfl(sy, src, 64); qz_ = __shfl(sz, src, 64); qb_ = __shfl(bound, src, 64);
                 }
                 int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                if (kq == 1) {                            // the common case, with compile-time LDS offsets
+                if (cold) {
+                    const float t1 = bound * 0.5f, t2 = bound * 0.25f, t3 = bound * 0.125f;
+                    for (int seg = 0; seg < 2; seg++) {
+                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                        int j = jb;
+                        for (; j + 4 <= je; j += 4) {         // four LDS reads in flight
+                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                            float d0, d1, d2v, d3;
+                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                            c0 += ((d0 <= bound) ? 1 : 0) + ((d1 <= bound) ? 1 : 0) + ((d2v <= bound) ? 1 : 0) + ((d3 <= bound) ? 1 : 0);
+                            c1 += ((d0 <= t1) ? 1 : 0) + ((d1 <= t1) ? 1 : 0) + ((d2v <= t1) ? 1 : 0) + ((d3 <= t1) ? 1 : 0);
+                            c2 += ((d0 <= t2) ? 1 : 0) + ((d1 <= t2) ? 1 : 0) + ((d2v <= t2) ? 1 : 0) + ((d3 <= t2) ? 1 : 0);
+                            c3 += ((d0 <= t3) ? 1 : 0) + ((d1 <= t3) ? 1 : 0) + ((d2v <= t3) ? 1 : 0) + ((d3 <= t3) ? 1 : 0);
+                        }
+                        for (; j < je; j++) {
+                            float d; make_key(lpts[j], sx, sy, sz, d);
+                            c0 += (d <= bound) ? 1 : 0; c1 += (d <= t1) ? 1 : 0; c2 += (d <= t2) ? 1 : 0; c3 += (d <= t3) ? 1 : 0;
+                        }
+                    }
+                    tb = (c3 >= 5) ? t3 : ((c2 >= 5) ? t2 : ((c1 >= 5) ? t1 : bound));
+                    ccnt = (c3 >= 5) ? c3 : ((c2 >= 5) ? c2 : ((c1 >= 5) ? c1 : c0));
+                    c1 = 0; c2 = 0; c3 = 0;               // c0 = points inside `bound`, as in the other branches
+                } else if (kq == 1) {                     // the common case, with compile-time LDS offsets
                     for (int seg = 0; seg < 2; seg++) {
                         const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
                         int j = jb;
@@ -1475,10 +1508,52 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
                 }
                 int cnt = c0 + c1 + c2 + c3;
                 for (int m = nslot; m < 64; m <<= 1) cnt += __shfl_xor(cnt, m, 64);
+                if (!cold) ccnt = cnt;
                 if (prior_ok && cnt == 5) todo = false;
                 else if (fin && bound >= gatef && cnt < 5) { todo = false; certain_far = true; }
             }
-            // ---- sweep: lanes with a new, lost or missing neighbour examine the tile, near segment first
+            // ---- lanes with a new, lost or missing neighbour.  The insertion network costs ~45 VALU and a wave
+            // pays it whenever ANY lane inserts, i.e. at nearly every tile point; so the lanes first write down
+            // the tile positions inside tb (a second branch-free sweep; exactly ccnt of them, >= 5 by
+            // construction, so the 5 nearest are among them) and then insert their k-th candidates together:
+            // ~10 wave-wide insertions instead of one per tile point.
+            if (!(ablate & 1) && __ballot(todo)) {
+                const bool use_list = todo && ccnt <= kCand;
+                if (__ballot(use_list)) {
+                    int cc = 0;
+                    if (use_list) {
+                        for (int seg = 0; seg < 2; seg++) {
+                            const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                            int j = jb;
+                            for (; j + 4 <= je; j += 4) {     // four LDS reads in flight
+                                const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                                float d0, d1, d2v, d3;
+                                make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                                make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                                if (d0 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
+                                if (d1 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 1); cc++; }
+                                if (d2v <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 2); cc++; }
+                                if (d3 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 3); cc++; }
+                            }
+                            for (; j < je; j++) {
+                                float d; make_key(lpts[j], sx, sy, sz, d);
+                                if (d <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                    const int cmax = wave_max_i32(cc);
+                    // candidate k+1 is fetched while candidate k is inserted; slots past cc hold stale positions (clamped, unused)
+                    v4f mk = lpts[min((int)lcand[lane], kTilePts - 1)];
+                    for (int k = 0; k < cmax; k++) {
+                        const v4f mn_ = lpts[min((int)lcand[min(k + 1, kCand - 1) * 64 + lane], kTilePts - 1)];
+                        if (k < cc) consider(best, bound, gatef, mk, sx, sy, sz);
+                        mk = mn_;
+                    }
+                    todo = todo && !use_list;
+                }
+            }
+            // ---- full sweep for whoever is left (a candidate list that would not fit): the tile, near segment first
             if (!(ablate & 1) && __ballot(todo)) {
                 if (todo) {
                     for (int seg = 0; seg < 2; seg++) {
