@@ -175,8 +175,9 @@ int  s2m_time_iterations(s2m_handle h, const float pose[6], int reps, float* ms_
 
 /* Diagnostics: `launches` > 0: that many k_register passes at `pose`, the last one recorded (1 = the pass
  * that inherits its prior from whatever ran before, 3 = steady state at this pose). `launches` < 0: a real LM
- * loop from `pose` (-launches >= 2) whose launch number -launches is recorded, including the fused close of
- * the iteration before it. Per wave (up to 64 locality-sorted scan points) S2M_PROF_WORDS words:
+ * loop from `pose` exactly as s2m_optimize issues it, of which launch number N = -launches - 1 is recorded
+ * (N = 0: the first launch of a scan, searching without a prior), including the fused close of the
+ * iteration before it. Per wave (up to 64 locality-sorted scan points) S2M_PROF_WORDS words:
  * [0..3] wall clock (100 MHz) at start / after the search / after plane+Jacobian / at end; [4] search path
  * (1 LDS tile, 2 gather), [5] box rows, [6] points visited, [7] raw points; [8..12] ticks spent in
  * prior+box / row marking, points in the wave, staging, search; [13..15] path details; [16..22] wall clock

@@ -706,13 +706,22 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
     h->ctx_dirty = true;
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
-    if (launches < 0) {            // a real loop: R0 F0 R1 R2' ... and the recorded launch is number -launches, closing the one before it
+    if (launches < 0) {
+        // a real loop as enqueue_loop issues it (density re-split, R0 F0 R1 R2' ...); the recorded launch is number
+        // N = -launches - 1 (N = 0: the first launch of a scan), closing the iteration before it when the loop is fused
         const DevCtx* dc = h->dctx.as<DevCtx>(); DevState* st = h->state.as<DevState>();
-        hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, st, 0, 0);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, 0, 0);
-        for (int L = 1; L < -launches; L++)
-            hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, st, L, L >= 2 ? 1 : 0);
-        hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, st, -launches, 1);
+        const int nblocks = h->hctx.nblocks, N = -launches - 1;
+        const bool fuse = h->fuse_solve && nblocks <= h->fuse_max_blocks;
+        if (h->density_raw > 0) {
+            hipLaunchKernelGGL(k_wave_density, dim3((nblocks * (kBlock / 64) + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
+                               h->density_raw);
+            hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, dc, st);
+        }
+        for (int L = 0; L < N; L++) {
+            hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, (fuse && L >= 2) ? 1 : 0);
+            if (!fuse || L == 0) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
+        }
+        hipLaunchKernelGGL(k_register<true>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, N, (fuse && N >= 2) ? 1 : 0);
     }
     for (int rep = 0; rep < launches; rep++)
         hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);

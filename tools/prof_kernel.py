@@ -24,9 +24,12 @@ if os.environ.get("S2M_WAVES"):
         e1.transformTobeMapped = cfg["pose_init"].copy(); r1 = e1.scan2MapOptimization(); p1 = np.array(r1.pose, np.float32); e1.close()
         print("pose after launch 0:", p1 - cfg["pose_init"])
         w = eng.wave_profile(p1, launches=1).astype(np.int64)
-    elif mode == "iter0":
+    elif mode == "iter0":      # the first launch of a scan as the loop issues it (after the density re-split)
         eng.setScan(synth.to_xyzi(cfg["scan"]))
-        w = eng.wave_profile(cfg["pose_init"], launches=1).astype(np.int64)
+        w = eng.wave_profile(cfg["pose_init"], launches=-1).astype(np.int64)
+    elif mode.startswith("loop"):      # loopN: launch N of a real loop
+        eng.setScan(synth.to_xyzi(cfg["scan"]))
+        w = eng.wave_profile(cfg["pose_init"], launches=-(int(mode[4:]) + 1)).astype(np.int64)
     else:
         w = eng.wave_profile(cfg["pose_init"]).astype(np.int64)
     w = w[w[:, 0] > 0]

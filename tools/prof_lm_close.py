@@ -9,7 +9,7 @@ L = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 eng = s2m.MapOptimizationS2M(early_exit=0)
 eng.setInputCloud(synth.to_xyzi(cfg["map"])); eng.setScan(synth.to_xyzi(cfg["scan"]))
 for rep in range(2):
-    w = eng.wave_profile(cfg["pose_init"], launches=-L).astype(np.int64)
+    w = eng.wave_profile(cfg["pose_init"], launches=-(L + 1)).astype(np.int64)
     w = w[w[:, 0] > 0]
     t0 = w[:, 0].min()
     print("launch %d: %d waves, span %.2f us, start spread %.2f us" % (L, len(w), (w[:, 3].max() - t0) / 100.0, (w[:, 0].max() - t0) / 100.0))
