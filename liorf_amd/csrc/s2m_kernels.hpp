@@ -847,43 +847,61 @@ __device__ __forceinline__ void store_trace(gptr<s2m_iter_trace> dst, const s2m_
 // in the order, of OpenCV's hal::QR32f (un-pivoted Householder QR in fp32 with unit-length reflectors,
 // the reflector kept as v/v[0] below the diagonal and re-expanded for the right-hand side, back
 // substitution; OpenCV >= 3.3).  The code is branch-free and LDS-free: all lanes run the reflector
-// arithmetic on their own column, lane l's result is broadcast with v_readlane, and the quotients
-// v[i]/v[0] (needed by lane l for storage and by lane 6 for the rhs) are computed once, wave-uniform.
-// A correctly rounded fp32 divide is ~10 instructions, so the count of divides and the absence of
-// divergent branches decide the latency of this serial chain.  Returns x in every lane.
+// arithmetic on their own column and lane l's result is broadcast with v_readlane.  The chain is bound
+// by instruction issue (a wave64 instruction occupies the SIMD for 4 cycles however few lanes matter,
+// a correctly rounded fp32 divide is ~10 instructions), so the independent divides of a reflector are
+// spread over the lanes - lane i divides element i - and the quotients v[i]/v[0] (needed by lane l for
+// storage and by lane 6 for the rhs) are computed once.  Returns x in every lane.
 __device__ __forceinline__ float lane_bcast(float v, int src_lane)
 {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
+// element `idx` (0..5, per lane) of a register array: a select chain, no scratch
+__device__ __forceinline__ float pick6(const float (&a)[6], int idx)
+{
+    float r = a[0];
+#pragma unroll
+    for (int i = 1; i < 6; i++) r = (idx == i) ? a[i] : r;
+    return r;
+}
+
 __device__ __forceinline__ bool solve6_qr_lanes(int lane, float (&col)[6], float (&x)[6])
 {
+    const int li = min(lane, 5);
 #pragma unroll
     for (int l = 0; l < 6; l++) {
+        // column l lives in lane l: bring its tail and the two norms to every lane
         float vl[6], u[6];
-        // reflector of column l (meaningful in lane l only; the other lanes' values are discarded)
         float nrm = 0.0f;
 #pragma unroll
         for (int i = 0; i < 6 - l; i++) { vl[i] = col[l + i]; nrm += vl[i] * vl[i]; }
         const float tmpV = vl[0];
         vl[0] = vl[0] + (vl[0] >= 0.0f ? 1.0f : -1.0f) * sqrtf(nrm);
         nrm = sqrtf(nrm + vl[0] * vl[0] - tmpV * tmpV);
+        nrm = lane_bcast(nrm, l);
 #pragma unroll
-        for (int i = 0; i < 6 - l; i++) vl[i] = lane_bcast(vl[i] / nrm, l);
+        for (int i = 0; i < 6; i++) vl[i] = (i < 6 - l) ? lane_bcast(vl[i], l) : 0.0f;
+        // the 6-l divides by the norm, one per lane, then the 5-l quotients v[i]/v[0], one per lane
+        const float q = pick6(vl, li) / nrm;
+#pragma unroll
+        for (int i = 0; i < 6 - l; i++) vl[i] = lane_bcast(q, i);
         const float hf = vl[0] * vl[0];
+        const float qu = pick6(vl, li) / vl[0];
         u[0] = 1.0f;
 #pragma unroll
-        for (int i = 1; i < 6 - l; i++) u[i] = vl[i] / vl[0];
-        // columns l..5: A -= 2 v (v^T A); rhs: the same reflector rebuilt from its stored form
-        float va = 0.0f, vb = 0.0f;
-#pragma unroll
-        for (int i = l; i < 6; i++) { va += vl[i - l] * col[i]; vb += u[i - l] * col[i]; }
+        for (int i = 1; i < 6 - l; i++) u[i] = lane_bcast(qu, i);
+        // columns l..5: A -= 2 v (v^T A); the rhs (lane 6) gets the same reflector rebuilt from its stored
+        // form, col -= ((2 u) (u^T col)) hf.  One dot product per lane, on the vector that lane needs.
         const bool is_col = lane >= l && lane < 6, is_rhs = lane == 6;
+        float w[6], dot = 0.0f;
+#pragma unroll
+        for (int i = l; i < 6; i++) { w[i - l] = is_rhs ? u[i - l] : vl[i - l]; dot += w[i - l] * col[i]; }
 #pragma unroll
         for (int i = l; i < 6; i++) {
-            const float ca = col[i] - 2.0f * vl[i - l] * va;
-            const float cb = col[i] - 2.0f * u[i - l] * vb * hf;
-            col[i] = is_col ? ca : (is_rhs ? cb : col[i]);
+            const float t = 2.0f * w[i - l] * dot;
+            const float c = col[i] - (is_rhs ? t * hf : t);
+            col[i] = (is_col || is_rhs) ? c : col[i];
         }
 #pragma unroll
         for (int i = 1; i < 6 - l; i++) col[l + i] = (lane == l) ? u[i] : col[l + i];
