@@ -2,8 +2,8 @@
 //
 // Owns the device memory (grow-only, sized by the actual point counts), builds the map's
 // uniform-grid index and the scan's locality order on the device, and runs the whole
-// <= max_iter LM loop as one captured hipGraph of {k_register, k_finalize} pairs so that a
-// scan costs one graph launch and one synchronisation.  There is no CPU fallback: without a
+// <= max_iter LM loop as one captured hipGraph (enqueue_loop) so that a scan costs one graph
+// launch and one synchronisation.  The voxel-grid stages that feed the path live in s2m_voxel.hip.  There is no CPU fallback: without a
 // gfx950 device every entry point fails with S2M_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 

@@ -589,37 +589,48 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // ------------------------------------------------------------------------------------------
 // k_register: one launch = one surfOptimization() pass (:1074-1143) fused with the matA/matB
 // row assembly of LMOptimization() (:1191-1235) and the first stage of the AtA / AtB
-// reduction (:1237-1239).  One lane = one scan point, one wave = 64 locality-sorted points.
+// reduction (:1237-1239); in the fused loop its prologue also closes the previous LM iteration
+// (lm_close_iteration below).  One lane = one scan point, one wave = up to 64 locality-sorted
+// points (8, 16 or 32 for chunks that k_chunk_parts / k_wave_density cut finer), 8 waves per
+// workgroup, <= 2 workgroups per CU.
 //
-// The L2 of this multi-die part starts cold at every kernel boundary (63 % TCC misses were
-// measured on an earlier version), so a dependent global round trip costs 0.5-1 us and the
-// kernel is organised around having few of them per wave:
+// The L2 of this multi-die part starts cold at every kernel boundary (40 % TCC misses per launch,
+// profiles/), so a dependent global round trip costs 0.5-1 us and the kernel is organised around
+// having few of them per wave:
 //
+//   round trip 0  the loop state block (kernel argument): `done`, the wave count, the pose
 //   round trip 1  scan point + PRIOR (the 5 neighbours this point had in the previous launch,
-//                 kept as coordinates + index; any 5 distinct map points would do).  Re-measured
-//                 at the new pose, their 5th distance - capped at the gate, beyond which nothing
-//                 is observable - is an exact upper bound on this launch's 5th-neighbour
-//                 distance: map rows and cells whose slab is farther away are never touched.
-//                 The LM loop revisits the same scan up to 30 times with an ever smaller pose
-//                 step, so from the second launch on the bound is tight.
+//                 kept as coordinates + index; any 5 distinct map points would do) + cached plane.
+//                 Re-measured at the new pose, the prior's 5th distance - capped at the gate,
+//                 beyond which nothing is observable - is an exact upper bound on this launch's
+//                 5th-neighbour distance: map rows and cells whose slab is farther away are never
+//                 touched.  The LM loop revisits the same scan up to 30 times with an ever smaller
+//                 pose step, so from the second launch on the bound is tight.
 //   (DPP)         wave bounding box of the transformed points -> box of grid cells (+1 halo)
 //   TILE path (compact waves, the common case)
 //   round trip 2  bounds of the box rows that some lane still needs
-//   round trip 3  those rows (contiguous runs of the cell-sorted map, coalesced, 8 rows in
-//                 flight) are filtered against the waves's point box grown by the largest
-//                 bound and compacted into the wave's LDS tile; every lane then sweeps the
-//                 tile (uniform loop, LDS broadcast reads).  A superset of a lane's
-//                 neighbourhood cannot change its gated result.
-//   GATHER path (sparse waves, big boxes)
+//   round trip 3  the non-empty ones among those rows (contiguous runs of the cell-sorted map, 8 rows
+//                 in flight, 16 lanes a row) are filtered against the waves's point box grown by the
+//                 largest bound and compacted into the wave's LDS tile.
+//                 verify: every lane counts the tile points inside its bound (branch-free; lanes of
+//                 a short wave share the work).  Exactly 5 with a complete prior: the ordered
+//                 neighbour set is the prior.  Fewer than 5 inside the gate: not gated.
+//                 otherwise: the lane lists the tile positions inside its radius (no prior: the
+//                 tightest of four radii that still holds 5 points) and the wave inserts the lanes'
+//                 k-th candidates together - a handful of insertion steps instead of one per tile
+//                 point.  A superset of a lane's neighbourhood cannot change its gated result.
+//   GATHER path (scattered waves: more than kRowMax box rows, a tile that would overflow)
 //   round trip 2  bounds of the <= 9 x-runs of each lane's own 3x3x3 neighbourhood
-//   round trip 3+ two points of every live run per batch (up to 18 loads in flight)
+//   round trip 3+ the runs, one after the other, the next one prefetched: count first, full
+//                 insertion pass only for lanes whose count is not 5
 //   -> exact top-5 by (d2, map index), coordinates carried along -> gate -> LS plane (re-used
 //   bit for bit when the ordered neighbour tuple is unchanged) -> inlier test -> weight ->
 //   Jacobian row -> 21+6+1 fp64 products per lane -> recursive-halving wave reduction + LDS
-//   across the 4 waves -> one partial per workgroup.
+//   across the 8 waves -> one partial row per workgroup, in the slot of this launch's parity.
 //
-// No barrier is needed until the final reduction: a wave only reads LDS it wrote itself.
-// combineOptimizationCoeffs() (:1145-1156) has no counterpart: rejected lanes contribute zeros.
+// No barrier is needed until the final reduction (and the two inside the fused close): a wave only
+// reads LDS it wrote itself.  combineOptimizationCoeffs() (:1145-1156) has no counterpart:
+// rejected lanes contribute zeros.
 // ------------------------------------------------------------------------------------------
 constexpr int kTilePts = 320;        // points per wave tile (5 KiB) after filtering
 constexpr int kTileRaw = 448;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
