@@ -230,6 +230,34 @@ int  s2m_make_scancontext(s2m_handle h, const void* pts, size_t n, size_t stride
                           double desc[S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR],
                           double ringkey[S2M_SC_NUM_RING]);
 
+/* ---- ScanContext matching ----------------------------------------------
+ * The SCManager's containers (reference include/Scancontext.h:102-113) kept on the device, and
+ * SCManager::detectLoopClosureID (include/Scancontext.cpp:253-344) with distanceBtnScanContext /
+ * fastAlignUsingVkey / distDirectSC (:69-148) as one kernel. Key frames are numbered in the order they are
+ * added. The reference rebuilds its ring-key kd-tree every 10th detection (TREE_MAKING_PERIOD_); the same
+ * staleness is kept: between rebuilds the search sees the key frames that existed at the last rebuild,
+ * minus the 30 most recent (NUM_EXCLUDE_RECENT). The 3 ring-key neighbours (NUM_CANDIDATES_FROM_TREE) are an
+ * exact fp32 3-NN in nanoflann's accumulation order; equal distances go to the lower index. */
+typedef struct s2m_sc_match {
+    double  min_dist;        /* best distanceBtnScanContext over the candidates (10000000 if none)  */
+    int32_t nn_idx;          /* its key frame                                                        */
+    int32_t nn_align;        /* its column shift (yaw difference in units of 6 degrees)             */
+    int32_t cand_idx[3];     /* ring-key neighbours, ascending distance                              */
+    float   cand_d2[3];      /* their squared ring-key distances                                     */
+} s2m_sc_match;
+int  s2m_sc_reset(s2m_handle h);
+int  s2m_sc_size(s2m_handle h);                                   /* key frames stored, or a negative status */
+/* makeAndSaveScancontextAndKeys(scan) (:236-250): descriptor, ring key and sector key of a host cloud, appended. */
+int  s2m_sc_add_scan(s2m_handle h, const void* pts, size_t n, size_t stride_bytes);
+/* The same for a descriptor computed elsewhere (20x60 row-major doubles). */
+int  s2m_sc_add_descriptor(s2m_handle h, const double desc[S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR]);
+/* detectLoopClosureID() for the newest key frame: *loop_id = matching key frame or -1, *yaw_diff_rad as the
+ * reference returns it (also when there is no loop); `detail` (optional) receives the intermediate values. */
+int  s2m_sc_detect_loop(s2m_handle h, int32_t* loop_id, float* yaw_diff_rad, s2m_sc_match* detail);
+/* distanceBtnScanContext(query, candidate k) for m stored candidates at once (one workgroup each): the
+ * batched form in which this row is worth running on a GPU. */
+int  s2m_sc_distance(s2m_handle h, int32_t query_idx, const int32_t* cand_idx, int32_t m, double* dist, int32_t* shift);
+
 #ifdef __cplusplus
 }
 #endif

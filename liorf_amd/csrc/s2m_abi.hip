@@ -51,6 +51,10 @@ struct s2m_context {
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
     // voxel-grid stages that feed the path (section 8(f) F1/F2): staging for host clouds, transformed key frames, filtered clouds
     DevBuf vox_in, vox_out, frames_xf, scan_ds, map_ds;
+    // ScanContext store (SCManager's containers, section 8(f) F3): descriptors, fp32 ring keys, sector keys, by key-frame index
+    DevBuf sc_store_desc, sc_store_ring, sc_store_sector, sc_cand, sc_res;
+    size_t sc_n = 0, sc_cap = 0, sc_n_search = 0;
+    int    sc_counter = 0;             // tree_making_period_conter (include/Scancontext.cpp:270-283)
     VoxWorkspace* vox = nullptr;
 
     DevCtx hctx{};
@@ -449,6 +453,60 @@ int download_records(s2m_context* h, const DevBuf& src, size_t n, void* out, siz
     return S2M_OK;
 }
 
+// ---- ScanContext store ---------------------------------------------------------------------------
+constexpr size_t kScDesc = (size_t)S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR;
+
+// grow-with-copy (ensure() alone would drop the contents)
+int sc_reserve(s2m_context* h, size_t want)
+{
+    if (want <= h->sc_cap) return S2M_OK;
+    size_t cap = h->sc_cap ? h->sc_cap : 256;
+    while (cap < want) cap *= 2;
+    struct Part { DevBuf* b; size_t elem; } parts[3] = { { &h->sc_store_desc, sizeof(double) * kScDesc },
+                                                         { &h->sc_store_ring, sizeof(float) * S2M_SC_NUM_RING },
+                                                         { &h->sc_store_sector, sizeof(double) * S2M_SC_NUM_SECTOR } };
+    for (Part& p : parts) {
+        void* np = nullptr;
+        S2M_HIP(h, hipMalloc(&np, p.elem * cap));
+        if (h->sc_n) S2M_HIP(h, hipMemcpyAsync(np, p.b->p, p.elem * h->sc_n, hipMemcpyDeviceToDevice, h->stream));
+        S2M_HIP(h, hipStreamSynchronize(h->stream));
+        if (p.b->p) S2M_HIP(h, hipFree(p.b->p));
+        p.b->p = np; p.b->cap = p.elem * cap;
+    }
+    h->sc_cap = cap;
+    return S2M_OK;
+}
+
+// descriptor + ring key are in h->sc_out (device): append them as key frame sc_n
+int sc_append_from_out(s2m_context* h)
+{
+    int rc = sc_reserve(h, h->sc_n + 1);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sc_append, dim3(1), dim3(kScThreads), 0, h->stream, (const double*)h->sc_out.as<double>(),
+                       h->sc_store_desc.as<double>(), h->sc_store_ring.as<float>(), h->sc_store_sector.as<double>(), (int)h->sc_n);
+    S2M_HIP(h, hipGetLastError());
+    h->sc_n++;
+    return S2M_OK;
+}
+
+// SCManager::makeScancontext + ring key of a host cloud into h->sc_out (device)
+int sc_build_descriptor(s2m_context* h, const void* pts, size_t n, size_t stride_bytes)
+{
+    S2M_HIP(h, hipMemsetAsync(h->sc_bins.p, 0, sizeof(uint32_t) * kScDesc, h->stream));
+    if (n > 0) {
+        int rc = ensure(h, h->raw_scan, n * stride_bytes);
+        if (rc) return rc;
+        S2M_HIP(h, hipMemcpyAsync(h->raw_scan.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
+        const int blocks = std::min((int)((n + 255) / 256), 1024);
+        hipLaunchKernelGGL(k_sc_polar_max, dim3(blocks), dim3(256), 0, h->stream,
+                           (const unsigned char*)h->raw_scan.as<unsigned char>(), stride_bytes, (int)n, h->sc_bins.as<uint32_t>());
+    }
+    hipLaunchKernelGGL(k_sc_finish, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)h->sc_bins.as<uint32_t>(),
+                       h->sc_out.as<double>(), h->sc_out.as<double>() + kScDesc);
+    S2M_HIP(h, hipGetLastError());
+    return S2M_OK;
+}
+
 }  // namespace
 
 // =============================================================================================
@@ -549,7 +607,8 @@ int s2m_destroy(s2m_handle h)
                        &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->prior_valid, &h->plane_cache, &h->plane_state, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out,
-                       &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds };
+                       &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds,
+                       &h->sc_store_desc, &h->sc_store_ring, &h->sc_store_sector, &h->sc_cand, &h->sc_res };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     vox_destroy(h->vox);
     if (h->h_state) (void)hipHostFree(h->h_state);
@@ -973,21 +1032,102 @@ int s2m_make_scancontext(s2m_handle h, const void* pts, size_t n, size_t stride_
     if (rc) return rc;
     if (!desc || !ringkey) return S2M_ERR_INVALID_ARG;
     S2M_HIP(h, hipSetDevice(h->device));
-    S2M_HIP(h, hipMemsetAsync(h->sc_bins.p, 0, sizeof(uint32_t) * 1200, h->stream));
-    if (n > 0) {
-        if ((rc = ensure(h, h->raw_scan, n * stride_bytes))) return rc;
-        S2M_HIP(h, hipMemcpyAsync(h->raw_scan.p, pts, n * stride_bytes, hipMemcpyHostToDevice, h->stream));
-        const int blocks = std::min((int)((n + 255) / 256), 1024);
-        hipLaunchKernelGGL(k_sc_polar_max, dim3(blocks), dim3(256), 0, h->stream,
-                           (const unsigned char*)h->raw_scan.as<unsigned char>(), stride_bytes, (int)n, h->sc_bins.as<uint32_t>());
-    }
-    hipLaunchKernelGGL(k_sc_finish, dim3(1), dim3(64), 0, h->stream, (const uint32_t*)h->sc_bins.as<uint32_t>(),
-                       h->sc_out.as<double>(), h->sc_out.as<double>() + 1200);
-    S2M_HIP(h, hipGetLastError());
+    if ((rc = sc_build_descriptor(h, pts, n, stride_bytes))) return rc;
     S2M_HIP(h, hipMemcpyAsync(h->h_sc, h->sc_out.p, sizeof(double) * 1220, hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
     memcpy(desc, h->h_sc, sizeof(double) * 1200);
     memcpy(ringkey, h->h_sc + 1200, sizeof(double) * 20);
+    return S2M_OK;
+}
+
+// ---- section 8(f) row F3: the SCManager loop detector ---------------------------------------------
+
+int s2m_sc_reset(s2m_handle h)
+{
+    if (!h) return S2M_ERR_INVALID_ARG;
+    h->sc_n = 0; h->sc_n_search = 0; h->sc_counter = 0;
+    return S2M_OK;
+}
+
+int s2m_sc_size(s2m_handle h) { return h ? (int)h->sc_n : S2M_ERR_INVALID_ARG; }
+
+int s2m_sc_add_scan(s2m_handle h, const void* pts, size_t n, size_t stride_bytes)
+{
+    int rc = check_records(h, pts, n, stride_bytes);
+    if (rc) return rc;
+    S2M_HIP(h, hipSetDevice(h->device));
+    if ((rc = sc_build_descriptor(h, pts, n, stride_bytes))) return rc;
+    if ((rc = sc_append_from_out(h))) return rc;
+    S2M_HIP(h, hipStreamSynchronize(h->stream));          // the caller's cloud is free again
+    return S2M_OK;
+}
+
+int s2m_sc_add_descriptor(s2m_handle h, const double desc[S2M_SC_NUM_RING * S2M_SC_NUM_SECTOR])
+{
+    if (!h || !desc) return S2M_ERR_INVALID_ARG;
+    S2M_HIP(h, hipSetDevice(h->device));
+    // ring key = row means, as makeRingkeyFromScancontext (:198-211) / k_sc_finish compute them
+    memcpy(h->h_sc, desc, sizeof(double) * kScDesc);
+    for (int r = 0; r < S2M_SC_NUM_RING; r++) {
+        double a = 0.0;
+        for (int k = 0; k < S2M_SC_NUM_SECTOR; k++) a += desc[r * S2M_SC_NUM_SECTOR + k];
+        h->h_sc[kScDesc + r] = a / 60.0;
+    }
+    S2M_HIP(h, hipMemcpyAsync(h->sc_out.p, h->h_sc, sizeof(double) * 1220, hipMemcpyHostToDevice, h->stream));
+    int rc = sc_append_from_out(h);
+    if (rc) return rc;
+    S2M_HIP(h, hipStreamSynchronize(h->stream));          // h_sc is reused by the next call
+    return S2M_OK;
+}
+
+int s2m_sc_detect_loop(s2m_handle h, int32_t* loop_id, float* yaw_diff_rad, s2m_sc_match* detail)
+{
+    if (!h || !loop_id || !yaw_diff_rad) return S2M_ERR_INVALID_ARG;
+    *loop_id = -1; *yaw_diff_rad = 0.0f;
+    if (detail) { memset(detail, 0, sizeof(*detail)); detail->min_dist = 10000000; }
+    constexpr int NUM_EXCLUDE_RECENT = 30, TREE_MAKING_PERIOD = 10;       // Scancontext.h:89, :99
+    if ((int)h->sc_n < NUM_EXCLUDE_RECENT + 1) return S2M_OK;              // :263-267
+    // the reference rebuilds its kd-tree every TREE_MAKING_PERIOD_ calls; between rebuilds the search sees the older set
+    if (h->sc_counter % TREE_MAKING_PERIOD == 0) h->sc_n_search = h->sc_n - NUM_EXCLUDE_RECENT;
+    h->sc_counter = h->sc_counter + 1;
+    S2M_HIP(h, hipSetDevice(h->device));
+    int rc = ensure(h, h->sc_res, sizeof(ScDetectOut));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sc_detect, dim3(1), dim3(kScThreads), 0, h->stream, (const double*)h->sc_store_desc.as<double>(),
+                       (const float*)h->sc_store_ring.as<float>(), (const double*)h->sc_store_sector.as<double>(),
+                       (int)h->sc_n, (int)h->sc_n_search, h->sc_res.as<ScDetectOut>());
+    S2M_HIP(h, hipGetLastError());
+    ScDetectOut o;
+    S2M_HIP(h, hipMemcpyAsync(&o, h->sc_res.p, sizeof(o), hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    *loop_id = o.loop_id; *yaw_diff_rad = o.yaw_diff_rad;
+    if (detail) {
+        detail->min_dist = o.min_dist; detail->nn_idx = o.nn_idx; detail->nn_align = o.nn_align;
+        for (int k = 0; k < 3; k++) { detail->cand_idx[k] = o.cand_idx[k]; detail->cand_d2[k] = o.cand_d2[k]; }
+    }
+    return S2M_OK;
+}
+
+int s2m_sc_distance(s2m_handle h, int32_t query_idx, const int32_t* cand_idx, int32_t m, double* dist, int32_t* shift)
+{
+    if (!h || m < 0 || (m > 0 && (!cand_idx || !dist || !shift))) return S2M_ERR_INVALID_ARG;
+    if (query_idx < 0 || (size_t)query_idx >= h->sc_n) return fail(h, S2M_ERR_INVALID_ARG, "query index outside the descriptor store");
+    for (int32_t k = 0; k < m; k++)
+        if (cand_idx[k] < 0 || (size_t)cand_idx[k] >= h->sc_n) return fail(h, S2M_ERR_INVALID_ARG, "candidate index outside the descriptor store");
+    if (m == 0) return S2M_OK;
+    S2M_HIP(h, hipSetDevice(h->device));
+    const size_t off_d = ((sizeof(int32_t) * (size_t)m + 15) & ~(size_t)15), off_s = off_d + sizeof(double) * (size_t)m;
+    int rc = ensure(h, h->sc_cand, off_s + sizeof(int32_t) * (size_t)m);
+    if (rc) return rc;
+    unsigned char* base = h->sc_cand.as<unsigned char>();
+    S2M_HIP(h, hipMemcpyAsync(base, cand_idx, sizeof(int32_t) * (size_t)m, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_sc_distance_batch, dim3((unsigned)m), dim3(kScThreads), 0, h->stream, (const double*)h->sc_store_desc.as<double>(),
+                       (const double*)h->sc_store_sector.as<double>(), (int)query_idx, (const int32_t*)base,
+                       (double*)(base + off_d), (int32_t*)(base + off_s));
+    S2M_HIP(h, hipGetLastError());
+    S2M_HIP(h, hipMemcpyAsync(dist, base + off_d, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipMemcpyAsync(shift, base + off_s, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
     return S2M_OK;
 }
 

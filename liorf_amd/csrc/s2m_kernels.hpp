@@ -1931,4 +1931,193 @@ __global__ __launch_bounds__(64) void k_sc_finish(const uint32_t* __restrict__ b
     ringkey[r] = s / 60.0;                                                 // row mean (:198-211)
 }
 
+// ------------------------------------------------------------------------------------------
+// ScanContext matching (reference include/Scancontext.cpp:69-148,
+// 214-344).  The SCManager's containers live on the device as three arrays indexed by key-frame
+// number: descriptors [n][20*60] fp64 (ring-major), ring keys [n][20] fp32 (eig2stdvec, :62-66),
+// sector keys [n][60] fp64.  Sizes are tiny (a descriptor is 9.6 KB), so one workgroup does a whole
+// detectLoopClosureID(); the batched kernel runs one workgroup per candidate.  All sums run left to
+// right in fp64 like the oracle's restatement, so distances are bit-identical to it.
+// ------------------------------------------------------------------------------------------
+constexpr int kScThreads = 256;
+constexpr int kScShifts = 7;           // 1 + 2 * round(0.5 * SEARCH_RATIO * 60) (:122-129, Scancontext.h:93)
+
+struct ScDetectOut {                   // mirrors s2m_sc_match + loop id / yaw
+    double  min_dist;
+    int32_t loop_id, nn_idx, nn_align;
+    float   yaw_diff_rad;
+    int32_t cand_idx[3];
+    float   cand_d2[3];
+};
+
+// makeAndSaveScancontextAndKeys (:236-250): descriptor + ring key (as k_sc_finish left them) into slot `idx`
+__global__ __launch_bounds__(kScThreads) void k_sc_append(const double* __restrict__ desc_ring, double* __restrict__ store_desc,
+                                                          float* __restrict__ store_ring, double* __restrict__ store_sector, int idx)
+{
+    constexpr int NR = S2M_SC_NUM_RING, NS = S2M_SC_NUM_SECTOR;
+    double* d = store_desc + (size_t)idx * NR * NS;
+    for (int k = threadIdx.x; k < NR * NS; k += kScThreads) d[k] = desc_ring[k];
+    if (threadIdx.x < NR) store_ring[(size_t)idx * NR + threadIdx.x] = (float)desc_ring[NR * NS + threadIdx.x];
+    if (threadIdx.x < NS) {                                                // makeSectorkeyFromScancontext (:214-227)
+        double a = 0.0;
+        for (int r = 0; r < NR; r++) a += desc_ring[r * NS + threadIdx.x];
+        store_sector[(size_t)idx * NS + threadIdx.x] = a / (double)NR;
+    }
+}
+
+struct ScShared {
+    double vnorm[S2M_SC_NUM_SECTOR];                     // fastAlignUsingVkey: ||vkey1 - circshift(vkey2, s)||
+    double sim[kScShifts][S2M_SC_NUM_SECTOR];            // per (shift, sector): cosine similarity
+    int    eff[kScShifts][S2M_SC_NUM_SECTOR];            // ... and whether the sector pair counts
+    double dist[kScShifts];
+    int    shifts[kScShifts];
+};
+
+// distanceBtnScanContext(sc1, sc2) (:116-148) by one workgroup; result valid in thread 0.
+__device__ __forceinline__ void sc_distance_block(const double* __restrict__ sc1, const double* __restrict__ v1,
+                                                  const double* __restrict__ sc2, const double* __restrict__ v2,
+                                                  ScShared& sh, double& dist_out, int& shift_out)
+{
+    constexpr int NR = S2M_SC_NUM_RING, NS = S2M_SC_NUM_SECTOR;
+    const int t = threadIdx.x;
+    __syncthreads();                                     // the scratch may still be read from a previous call
+    if (t < NS) {                                        // fastAlignUsingVkey (:94-113), one shift per thread
+        double a = 0.0;
+        for (int j = 0; j < NS; j++) {
+            const double d = v1[j] - v2[(j - t + NS) % NS];
+            a += d * d;
+        }
+        sh.vnorm[t] = sqrt(a);
+    }
+    __syncthreads();
+    if (t == 0) {
+        int a0 = 0;
+        double best = 10000000;
+        for (int s = 0; s < NS; s++) if (sh.vnorm[s] < best) { a0 = s; best = sh.vnorm[s]; }
+        // search space a0, a0 +- 1..3 (mod 60), ascending (:122-129)
+        int sp[kScShifts];
+        sp[0] = a0;
+        for (int ii = 1; ii <= (kScShifts - 1) / 2; ii++) { sp[2 * ii - 1] = (a0 + ii + NS) % NS; sp[2 * ii] = (a0 - ii + NS) % NS; }
+        for (int a = 1; a < kScShifts; a++) {            // insertion sort
+            const int v = sp[a];
+            int b = a - 1;
+            while (b >= 0 && sp[b] > v) { sp[b + 1] = sp[b]; b--; }
+            sp[b + 1] = v;
+        }
+        for (int k = 0; k < kScShifts; k++) sh.shifts[k] = sp[k];
+    }
+    __syncthreads();
+    for (int task = t; task < kScShifts * NS; task += kScThreads) {       // distDirectSC (:69-91), one sector pair per task
+        const int k = task / NS, j = task - k * NS;
+        const int j2 = (j - sh.shifts[k] + NS) % NS;                      // circshift (:39-59)
+        double n1 = 0.0, n2 = 0.0, dot = 0.0;
+        for (int r = 0; r < NR; r++) {
+            const double a = sc1[r * NS + j], b = sc2[r * NS + j2];
+            n1 += a * a; n2 += b * b; dot += a * b;
+        }
+        n1 = sqrt(n1); n2 = sqrt(n2);
+        const bool skip = (n1 == 0) | (n2 == 0);
+        sh.eff[k][j] = skip ? 0 : 1;
+        sh.sim[k][j] = skip ? 0.0 : dot / (n1 * n2);
+    }
+    __syncthreads();
+    if (t < kScShifts) {
+        int num_eff = 0;
+        double sum = 0;
+        for (int j = 0; j < NS; j++) if (sh.eff[t][j]) { sum = sum + sh.sim[t][j]; num_eff = num_eff + 1; }
+        sh.dist[t] = 1.0 - sum / (double)num_eff;         // 0/0 = NaN when no sector counts, as in the reference
+    }
+    __syncthreads();
+    if (t == 0) {
+        int argmin_shift = 0;
+        double min_sc_dist = 10000000;
+        for (int k = 0; k < kScShifts; k++) if (sh.dist[k] < min_sc_dist) { argmin_shift = sh.shifts[k]; min_sc_dist = sh.dist[k]; }
+        dist_out = min_sc_dist; shift_out = argmin_shift;
+    }
+}
+
+// distanceBtnScanContext of descriptor `query` against cand[0..m): one workgroup per candidate
+__global__ __launch_bounds__(kScThreads) void k_sc_distance_batch(const double* __restrict__ store_desc, const double* __restrict__ store_sector,
+                                                                  int query, const int32_t* __restrict__ cand, double* __restrict__ dist,
+                                                                  int32_t* __restrict__ shift)
+{
+    constexpr int NR = S2M_SC_NUM_RING, NS = S2M_SC_NUM_SECTOR;
+    __shared__ ScShared sh;
+    const int c = cand[blockIdx.x];
+    double d = 0.0; int s = 0;
+    sc_distance_block(store_desc + (size_t)query * NR * NS, store_sector + (size_t)query * NS,
+                      store_desc + (size_t)c * NR * NS, store_sector + (size_t)c * NS, sh, d, s);
+    if (threadIdx.x == 0) { dist[blockIdx.x] = d; shift[blockIdx.x] = s; }
+}
+
+// detectLoopClosureID (:253-344) for the newest descriptor (index n_total - 1) against the ring keys
+// [0, n_search) (the contents of the reference's kd-tree at its last rebuild).
+__global__ __launch_bounds__(kScThreads) void k_sc_detect(const double* __restrict__ store_desc, const float* __restrict__ store_ring,
+                                                          const double* __restrict__ store_sector, int n_total, int n_search,
+                                                          ScDetectOut* __restrict__ out)
+{
+    constexpr int NR = S2M_SC_NUM_RING, NS = S2M_SC_NUM_SECTOR;
+    __shared__ ScShared sh;
+    __shared__ float s_d2[kScThreads][3];
+    __shared__ int   s_ix[kScThreads][3];
+    __shared__ int   s_cand[3];
+    const int t = threadIdx.x, q = n_total - 1;
+    // exact 3-NN over the fp32 ring keys, accumulation order of nanoflann's L2_Adaptor (groups of four);
+    // ties go to the lower index
+    float bd[3] = { INFINITY, INFINITY, INFINITY };
+    int bi[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff };
+    const float* qk = store_ring + (size_t)q * NR;
+    for (int i = t; i < n_search; i += kScThreads) {
+        const float* b = store_ring + (size_t)i * NR;
+        float result = 0.0f;
+        for (int d = 0; d < NR; d += 4) {
+            const float d0 = qk[d] - b[d], d1 = qk[d + 1] - b[d + 1], d2 = qk[d + 2] - b[d + 2], d3 = qk[d + 3] - b[d + 3];
+            result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        if (result < bd[2]) {                             // i ascends per thread: an equal distance stays behind
+            bd[2] = result; bi[2] = i;
+            if (bd[2] < bd[1]) { const float a = bd[1]; bd[1] = bd[2]; bd[2] = a; const int b2 = bi[1]; bi[1] = bi[2]; bi[2] = b2; }
+            if (bd[1] < bd[0]) { const float a = bd[0]; bd[0] = bd[1]; bd[1] = a; const int b2 = bi[0]; bi[0] = bi[1]; bi[1] = b2; }
+        }
+    }
+    for (int k = 0; k < 3; k++) { s_d2[t][k] = bd[k]; s_ix[t][k] = bi[k]; }
+    __syncthreads();
+    if (t == 0) {
+        float fd[3] = { INFINITY, INFINITY, INFINITY };
+        int fi[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff };
+        for (int u = 0; u < kScThreads; u++)
+            for (int k = 0; k < 3; k++) {
+                const float d = s_d2[u][k]; const int ix = s_ix[u][k];
+                if (ix == 0x7fffffff) continue;
+                int pos = 3;
+                while (pos > 0 && (fd[pos - 1] > d || (fd[pos - 1] == d && fi[pos - 1] > ix))) pos--;
+                if (pos < 3) {
+                    for (int m = 2; m > pos; m--) { fd[m] = fd[m - 1]; fi[m] = fi[m - 1]; }
+                    fd[pos] = d; fi[pos] = ix;
+                }
+            }
+        for (int k = 0; k < 3; k++) {
+            const bool have = fi[k] != 0x7fffffff;        // fewer keys than candidates: index 0 (:289 zero-initialised)
+            s_cand[k] = have ? fi[k] : 0;
+            out->cand_idx[k] = s_cand[k];
+            out->cand_d2[k] = have ? fd[k] : 0.0f;
+        }
+    }
+    __syncthreads();
+    double min_dist = 10000000;
+    int nn_align = 0, nn_idx = 0;
+    for (int c = 0; c < 3; c++) {                         // :302-316
+        double d = 0.0; int s = 0;
+        const int ci = s_cand[c];
+        sc_distance_block(store_desc + (size_t)q * NR * NS, store_sector + (size_t)q * NS,
+                          store_desc + (size_t)ci * NR * NS, store_sector + (size_t)ci * NS, sh, d, s);
+        if (t == 0 && d < min_dist) { min_dist = d; nn_align = s; nn_idx = ci; }
+    }
+    if (t == 0) {
+        out->min_dist = min_dist; out->nn_idx = nn_idx; out->nn_align = nn_align;
+        out->loop_id = (min_dist < 0.3) ? nn_idx : -1;    // SC_DIST_THRES (Scancontext.h:95)
+        out->yaw_diff_rad = (float)((double)(float)((double)nn_align * (360.0 / 60.0)) * M_PI / 180.0);   // deg2rad(float) (:17-20, :338)
+    }
+}
+
 }  // namespace s2m

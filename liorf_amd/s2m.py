@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
     "s2m_transform_cloud",
+    "s2m_sc_reset", "s2m_sc_size", "s2m_sc_add_scan", "s2m_sc_add_descriptor", "s2m_sc_detect_loop", "s2m_sc_distance",
 ]
 S2M_WARN_LEAF_TOO_SMALL = 1
 
@@ -59,6 +60,11 @@ class Result(C.Structure):
 class IterTrace(C.Structure):
     _fields_ = [("n_sel", C.c_int32), ("stepped", C.c_int32), ("delta", C.c_float * 6),
                 ("pose", C.c_float * 6), ("deltaR", C.c_float), ("deltaT", C.c_float)]
+
+
+class ScMatch(C.Structure):
+    _fields_ = [("min_dist", C.c_double), ("nn_idx", C.c_int32), ("nn_align", C.c_int32),
+                ("cand_idx", C.c_int32 * 3), ("cand_d2", C.c_float * 3)]
 
 
 class S2MError(RuntimeError):
@@ -126,6 +132,13 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_extract_cloud.argtypes = [vp, C.c_int, C.POINTER(vp), szp, C.c_size_t, C.c_int, fp, C.c_float,
                                     vp, C.c_size_t, C.c_size_t, szp]
     L.s2m_transform_cloud.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, vp, C.c_size_t]
+    dp, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.s2m_sc_reset.argtypes = [vp]
+    L.s2m_sc_size.argtypes = [vp]
+    L.s2m_sc_add_scan.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+    L.s2m_sc_add_descriptor.argtypes = [vp, dp]
+    L.s2m_sc_detect_loop.argtypes = [vp, i32p, fp, C.POINTER(ScMatch)]
+    L.s2m_sc_distance.argtypes = [vp, C.c_int32, i32p, C.c_int32, dp, i32p]
     if path is None:
         _LIB = L
     return L
@@ -381,6 +394,38 @@ class MapOptimizationS2M:
         if n < 0:
             self._check(n, "s2m_debug_wave_profile")
         return out[:n]
+
+    # -- SCManager (reference include/Scancontext.cpp), SURVEY.md section 8(f) row F3 --------------
+    def scReset(self):
+        self._check(self.lib.s2m_sc_reset(self.h), "s2m_sc_reset")
+
+    def scSize(self) -> int:
+        return self.lib.s2m_sc_size(self.h)
+
+    def makeAndSaveScancontextAndKeys(self, scan_down):
+        """Reference :236-250: descriptor + ring key + sector key of the cloud, appended to the device store."""
+        a, n, st = _records(scan_down)
+        self._check(self.lib.s2m_sc_add_scan(self.h, a.ctypes.data, n, st), "s2m_sc_add_scan")
+
+    def scAddDescriptor(self, desc):
+        d = np.ascontiguousarray(desc, np.float64).reshape(20, 60)
+        self._check(self.lib.s2m_sc_add_descriptor(self.h, d.ctypes.data_as(C.POINTER(C.c_double))), "s2m_sc_add_descriptor")
+
+    def detectLoopClosureID(self):
+        """Reference :253-344: (loop_id, yaw_diff_rad, ScMatch with the intermediate values)."""
+        lid, yaw, m = C.c_int32(-1), C.c_float(0), ScMatch()
+        self._check(self.lib.s2m_sc_detect_loop(self.h, C.byref(lid), C.byref(yaw), C.byref(m)), "s2m_sc_detect_loop")
+        return lid.value, yaw.value, m
+
+    def distanceBtnScanContext(self, query_idx: int, cand_idx):
+        """Reference :116-148 for stored key frames, batched over the candidates: (dist[m], shift[m])."""
+        c = np.ascontiguousarray(cand_idx, np.int32)
+        dist = np.zeros(len(c), np.float64)
+        shift = np.zeros(len(c), np.int32)
+        self._check(self.lib.s2m_sc_distance(self.h, query_idx, c.ctypes.data_as(C.POINTER(C.c_int32)), len(c),
+                                             dist.ctypes.data_as(C.POINTER(C.c_double)),
+                                             shift.ctypes.data_as(C.POINTER(C.c_int32))), "s2m_sc_distance")
+        return dist, shift
 
     def makeScancontext(self, scan):
         """SCManager::makeScancontext + makeRingkeyFromScancontext (reference include/Scancontext.cpp:151-211)."""

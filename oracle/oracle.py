@@ -98,6 +98,20 @@ def lib() -> C.CDLL:
         L.orc_xy2theta.restype = C.c_float
         L.orc_makeScancontext.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double)]
         L.orc_makeRingkeyFromScancontext.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        dp = C.POINTER(C.c_double)
+        L.orc_makeSectorkeyFromScancontext.argtypes = [dp, dp]
+        L.orc_distDirectSC_shifted.argtypes = [dp, dp, C.c_int]
+        L.orc_distDirectSC_shifted.restype = C.c_double
+        L.orc_fastAlignUsingVkey.argtypes = [dp, dp]
+        L.orc_distanceBtnScanContext.argtypes = [dp, dp, dp, C.POINTER(C.c_int)]
+        L.orc_sc_create.restype = vp
+        L.orc_sc_destroy.argtypes = [vp]
+        L.orc_sc_size.argtypes = [vp]
+        L.orc_sc_size.restype = C.c_size_t
+        L.orc_sc_add_descriptor.argtypes = [vp, dp]
+        L.orc_sc_add_scan.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
+        L.orc_sc_detectLoopClosureID.argtypes = [vp, fp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                                 C.POINTER(C.c_int * 3), C.POINTER(C.c_float * 3)]
         L.orc_voxelGrid.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_float, vp, C.c_size_t, C.c_size_t,
                                     C.POINTER(C.c_size_t)]
         L.orc_transformPointCloud.argtypes = [vp, C.c_size_t, C.c_size_t, fp, vp, C.c_size_t]
@@ -272,6 +286,70 @@ def make_scancontext(pts):
     lib().orc_makeScancontext(a.ctypes.data, n, st, dp)
     lib().orc_makeRingkeyFromScancontext(dp, key.ctypes.data_as(C.POINTER(C.c_double)))
     return desc, key
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def distance_btn_scancontext(sc1, sc2):
+    """distanceBtnScanContext (reference include/Scancontext.cpp:116-148): (dist, shift)."""
+    a = np.ascontiguousarray(sc1, np.float64).reshape(20, 60)
+    b = np.ascontiguousarray(sc2, np.float64).reshape(20, 60)
+    d, s = C.c_double(0), C.c_int(0)
+    lib().orc_distanceBtnScanContext(_dp(a), _dp(b), C.byref(d), C.byref(s))
+    return d.value, s.value
+
+
+def dist_direct_sc(sc1, sc2, shift: int = 0) -> float:
+    a = np.ascontiguousarray(sc1, np.float64).reshape(20, 60)
+    b = np.ascontiguousarray(sc2, np.float64).reshape(20, 60)
+    return lib().orc_distDirectSC_shifted(_dp(a), _dp(b), shift)
+
+
+def fast_align_vkey(sc1, sc2) -> int:
+    a = np.ascontiguousarray(sc1, np.float64).reshape(20, 60)
+    b = np.ascontiguousarray(sc2, np.float64).reshape(20, 60)
+    v1, v2 = np.zeros(60), np.zeros(60)
+    lib().orc_makeSectorkeyFromScancontext(_dp(a), _dp(v1))
+    lib().orc_makeSectorkeyFromScancontext(_dp(b), _dp(v2))
+    return lib().orc_fastAlignUsingVkey(_dp(v1), _dp(v2))
+
+
+class SCManager:
+    """The oracle's SCManager (reference include/Scancontext.cpp:236-344)."""
+
+    def __init__(self):
+        self.h = C.c_void_p(lib().orc_sc_create())
+
+    def close(self):
+        if self.h:
+            lib().orc_sc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        return lib().orc_sc_size(self.h)
+
+    def add_descriptor(self, desc):
+        d = np.ascontiguousarray(desc, np.float64).reshape(20, 60)
+        lib().orc_sc_add_descriptor(self.h, _dp(d))
+
+    def add_scan(self, pts):
+        a, n, st = _records(pts)
+        lib().orc_sc_add_scan(self.h, a.ctypes.data, n, st)
+
+    def detectLoopClosureID(self):
+        """(loop_id, yaw_diff_rad, dict of the intermediate values)"""
+        yaw, md, ni, na = C.c_float(0), C.c_double(0), C.c_int(0), C.c_int(0)
+        ci, cd = (C.c_int * 3)(), (C.c_float * 3)()
+        lid = lib().orc_sc_detectLoopClosureID(self.h, C.byref(yaw), C.byref(md), C.byref(ni), C.byref(na), C.byref(ci), C.byref(cd))
+        return lid, yaw.value, dict(min_dist=md.value, nn_idx=ni.value, nn_align=na.value, cand_idx=list(ci), cand_d2=list(cd))
 
 
 def voxel_grid(pts, leaf: float):

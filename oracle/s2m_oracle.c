@@ -1022,3 +1022,167 @@ void orc_transformPointCloud(const void* pts, size_t n, size_t stride_bytes, con
         memcpy(o, rec, out_stride_bytes >= 20 ? 20 : (out_stride_bytes >= 16 ? 16 : 12));
     }
 }
+
+/* ==== section 8(f) row F3: ScanContext matching (include/Scancontext.cpp:69-148, 214-344) =========
+ * Descriptors are 20 x 60 row-major doubles as orc_makeScancontext writes them (ring r, sector s at
+ * desc[r*60 + s]); the reference's Eigen::MatrixXd is column-major, which changes no arithmetic.
+ * [ext] Eigen's mean()/norm()/dot() on 20- and 60-vectors reduce in a vectorised order that depends on
+ * the Eigen version and instruction set; restated as plain left-to-right sums (differences ~1e-16
+ * relative).  nanoflann's kNN over the float ring keys is restated as brute force with the vendored
+ * L2_Adaptor's accumulation order (include/nanoflann.hpp:383-408: groups of four); equal distances,
+ * which the kd-tree would order by traversal, go to the lower index.
+ */
+#define SC_NR 20
+#define SC_NS 60
+
+void orc_makeSectorkeyFromScancontext(const double desc[SC_NR * SC_NS], double key[SC_NS])
+{
+    for (int s = 0; s < SC_NS; s++) {                                  /* :214-227 column mean */
+        double a = 0.0; for (int r = 0; r < SC_NR; r++) a += desc[r * SC_NS + s];
+        key[s] = a / (double)SC_NR;
+    }
+}
+
+/* distDirectSC(_sc1, circshift(_sc2, shift)) (:69-91 with :39-59): column j of the shifted matrix is
+ * column (j - shift) mod 60 of _sc2 */
+double orc_distDirectSC_shifted(const double sc1[SC_NR * SC_NS], const double sc2[SC_NR * SC_NS], int shift)
+{
+    int num_eff_cols = 0;
+    double sum_sector_similarity = 0;
+    for (int j = 0; j < SC_NS; j++) {
+        const int j2 = ((j - shift) % SC_NS + SC_NS) % SC_NS;
+        double n1 = 0.0, n2 = 0.0, dot = 0.0;
+        for (int r = 0; r < SC_NR; r++) {
+            const double a = sc1[r * SC_NS + j], b = sc2[r * SC_NS + j2];
+            n1 += a * a; n2 += b * b; dot += a * b;
+        }
+        n1 = sqrt(n1); n2 = sqrt(n2);
+        if ((n1 == 0) | (n2 == 0)) continue;                           /* :78-79 */
+        sum_sector_similarity = sum_sector_similarity + dot / (n1 * n2);   /* :81-83 */
+        num_eff_cols = num_eff_cols + 1;
+    }
+    const double sc_sim = sum_sector_similarity / num_eff_cols;       /* 0/0 = NaN when no sector counts */
+    return 1.0 - sc_sim;
+}
+
+int orc_fastAlignUsingVkey(const double vkey1[SC_NS], const double vkey2[SC_NS])
+{
+    int argmin_vkey_shift = 0;                                         /* :94-113 */
+    double min_veky_diff_norm = 10000000;
+    for (int shift = 0; shift < SC_NS; shift++) {
+        double a = 0.0;
+        for (int j = 0; j < SC_NS; j++) {
+            const double d = vkey1[j] - vkey2[((j - shift) % SC_NS + SC_NS) % SC_NS];
+            a += d * d;
+        }
+        const double cur = sqrt(a);
+        if (cur < min_veky_diff_norm) { argmin_vkey_shift = shift; min_veky_diff_norm = cur; }
+    }
+    return argmin_vkey_shift;
+}
+
+static int cmp_int(const void* a, const void* b) { return *(const int*)a - *(const int*)b; }
+
+/* distanceBtnScanContext (:116-148): SEARCH_RATIO 0.1 (Scancontext.h:93) */
+void orc_distanceBtnScanContext(const double sc1[SC_NR * SC_NS], const double sc2[SC_NR * SC_NS], double* dist, int* shift)
+{
+    double v1[SC_NS], v2[SC_NS];
+    orc_makeSectorkeyFromScancontext(sc1, v1);
+    orc_makeSectorkeyFromScancontext(sc2, v2);
+    const int a0 = orc_fastAlignUsingVkey(v1, v2);
+    const int SEARCH_RADIUS = (int)round(0.5 * 0.1 * SC_NS);
+    int space[1 + 2 * SC_NS], n = 0;
+    space[n++] = a0;
+    for (int ii = 1; ii < SEARCH_RADIUS + 1; ii++) {
+        space[n++] = (a0 + ii + SC_NS) % SC_NS;
+        space[n++] = (a0 - ii + SC_NS) % SC_NS;
+    }
+    qsort(space, (size_t)n, sizeof(int), cmp_int);
+    int argmin_shift = 0;
+    double min_sc_dist = 10000000;
+    for (int k = 0; k < n; k++) {
+        const double cur = orc_distDirectSC_shifted(sc1, sc2, space[k]);
+        if (cur < min_sc_dist) { argmin_shift = space[k]; min_sc_dist = cur; }
+    }
+    *dist = min_sc_dist; *shift = argmin_shift;
+}
+
+/* SCManager state (Scancontext.h:102-113) and detectLoopClosureID (:253-344) */
+struct orc_sc {
+    double* desc; float* invkey; size_t n, cap;
+    size_t n_search;            /* keys in the tree at its last rebuild */
+    int    counter;             /* tree_making_period_conter */
+};
+
+orc_sc* orc_sc_create(void) { return (orc_sc*)calloc(1, sizeof(orc_sc)); }
+void orc_sc_destroy(orc_sc* m) { if (m) { free(m->desc); free(m->invkey); free(m); } }
+size_t orc_sc_size(const orc_sc* m) { return m->n; }
+
+void orc_sc_add_descriptor(orc_sc* m, const double desc[SC_NR * SC_NS])   /* makeAndSaveScancontextAndKeys :236-250 */
+{
+    if (m->n == m->cap) {
+        m->cap = m->cap ? 2 * m->cap : 64;
+        m->desc = (double*)realloc(m->desc, m->cap * SC_NR * SC_NS * sizeof(double));
+        m->invkey = (float*)realloc(m->invkey, m->cap * SC_NR * sizeof(float));
+    }
+    memcpy(m->desc + m->n * SC_NR * SC_NS, desc, SC_NR * SC_NS * sizeof(double));
+    double key[SC_NR];
+    orc_makeRingkeyFromScancontext(desc, key);
+    for (int r = 0; r < SC_NR; r++) m->invkey[m->n * SC_NR + r] = (float)key[r];   /* eig2stdvec :62-66 */
+    m->n++;
+}
+
+void orc_sc_add_scan(orc_sc* m, const void* pts, size_t n, size_t stride_bytes)
+{
+    double desc[SC_NR * SC_NS];
+    orc_makeScancontext(pts, n, stride_bytes, desc);
+    orc_sc_add_descriptor(m, desc);
+}
+
+/* Returns loop_id (-1: none); also the values the reference computes on the way. cand_* hold the
+ * NUM_CANDIDATES_FROM_TREE (3) ring-key neighbours in ascending distance. */
+int orc_sc_detectLoopClosureID(orc_sc* m, float* yaw_diff_rad, double* min_dist_out, int* nn_idx_out, int* nn_align_out,
+                               int cand_idx[3], float cand_d2[3])
+{
+    const int NUM_EXCLUDE_RECENT = 30, NUM_CANDIDATES = 3, TREE_MAKING_PERIOD = 10;
+    const double SC_DIST_THRES = 0.3, PC_UNIT_SECTORANGLE = 360.0 / 60.0;
+    *yaw_diff_rad = 0.0f; *min_dist_out = 10000000; *nn_idx_out = 0; *nn_align_out = 0;
+    for (int k = 0; k < 3; k++) { cand_idx[k] = 0; cand_d2[k] = 0.0f; }
+    if ((int)m->n < NUM_EXCLUDE_RECENT + 1) return -1;                 /* :263-267 */
+    if (m->counter % TREE_MAKING_PERIOD == 0) m->n_search = m->n - NUM_EXCLUDE_RECENT;   /* :270-281 */
+    m->counter = m->counter + 1;
+
+    const float* q = m->invkey + (m->n - 1) * SC_NR;
+    const double* curr = m->desc + (m->n - 1) * SC_NR * SC_NS;
+    /* knn search (:288-296): exact 3-NN, ascending */
+    int nfound = 0;
+    for (size_t i = 0; i < m->n_search; i++) {
+        const float* b = m->invkey + i * SC_NR;
+        float result = 0.0f;
+        for (int d = 0; d < SC_NR; d += 4) {
+            const float d0 = q[d] - b[d], d1 = q[d + 1] - b[d + 1], d2 = q[d + 2] - b[d + 2], d3 = q[d + 3] - b[d + 3];
+            result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+        int pos = nfound < NUM_CANDIDATES ? nfound : NUM_CANDIDATES;
+        while (pos > 0 && cand_d2[pos - 1] > result) pos--;
+        if (pos < NUM_CANDIDATES) {
+            const int last = nfound < NUM_CANDIDATES ? nfound : NUM_CANDIDATES - 1;
+            for (int k = last; k > pos; k--) { cand_d2[k] = cand_d2[k - 1]; cand_idx[k] = cand_idx[k - 1]; }
+            cand_d2[pos] = result; cand_idx[pos] = (int)i;
+            if (nfound < NUM_CANDIDATES) nfound++;
+        }
+    }
+    /* fewer keys than candidates: the reference's index vector keeps its zero initialisation (:289) */
+    double min_dist = 10000000;
+    int nn_align = 0, nn_idx = 0;
+    for (int c = 0; c < NUM_CANDIDATES; c++) {                         /* :302-316 */
+        double dist; int align;
+        orc_distanceBtnScanContext(curr, m->desc + (size_t)cand_idx[c] * SC_NR * SC_NS, &dist, &align);
+        if (dist < min_dist) { min_dist = dist; nn_align = align; nn_idx = cand_idx[c]; }
+    }
+    int loop_id = -1;
+    if (min_dist < SC_DIST_THRES) loop_id = nn_idx;                    /* :322-324 */
+    *yaw_diff_rad = (float)((double)(float)(nn_align * PC_UNIT_SECTORANGLE) * M_PI / 180.0);   /* deg2rad(float) :17-20, :338 */
+    *min_dist_out = min_dist; *nn_idx_out = nn_idx; *nn_align_out = nn_align;
+    return loop_id;
+}

@@ -122,6 +122,20 @@ int      orc_voxelGrid(const void* pts, size_t n, size_t stride_bytes, float lea
 void     orc_transformPointCloud(const void* pts, size_t n, size_t stride_bytes, const float pose_xyzrpy[6],
                                  void* out, size_t out_stride_bytes);
 
+/* section 8(f) row F3: ScanContext matching (include/Scancontext.cpp:69-148, 214-344) */
+typedef struct orc_sc orc_sc;
+void     orc_makeSectorkeyFromScancontext(const double desc[20 * 60], double key[60]);
+double   orc_distDirectSC_shifted(const double sc1[20 * 60], const double sc2[20 * 60], int shift);
+int      orc_fastAlignUsingVkey(const double vkey1[60], const double vkey2[60]);
+void     orc_distanceBtnScanContext(const double sc1[20 * 60], const double sc2[20 * 60], double* dist, int* shift);
+orc_sc*  orc_sc_create(void);
+void     orc_sc_destroy(orc_sc* m);
+size_t   orc_sc_size(const orc_sc* m);
+void     orc_sc_add_descriptor(orc_sc* m, const double desc[20 * 60]);
+void     orc_sc_add_scan(orc_sc* m, const void* pts, size_t n, size_t stride_bytes);
+int      orc_sc_detectLoopClosureID(orc_sc* m, float* yaw_diff_rad, double* min_dist, int* nn_idx, int* nn_align,
+                                    int cand_idx[3], float cand_d2[3]);
+
 #ifdef __cplusplus
 }
 #endif

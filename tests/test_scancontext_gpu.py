@@ -1,0 +1,88 @@
+"""GPU parity of the ScanContext loop detector (reference
+include/Scancontext.cpp:69-148, 214-344) through the C ABI against the CPU oracle.  Bar: same loop ids,
+candidates and shifts; distances bit-identical (same fp64 operation order).  PARITY UNPINNED.
+"""
+import numpy as np
+import pytest
+
+from liorf_amd import s2m, synth
+from oracle import oracle as O
+from test_scancontext_cpu import make_descriptors, revisit
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    g = s2m.MapOptimizationS2M()
+    yield g
+    g.close()
+
+
+def test_detect_loop_sequence_matches_oracle(gpu):
+    descs = make_descriptors(340, seed=3)           # crosses the store's first growth (256)
+    gpu.scReset()
+    orc = O.SCManager()
+    loops = 0
+    for i, d in enumerate(descs):
+        if i >= 60 and i % 13 == 0:
+            d = revisit(descs[i - 50], shift=(11 * i) % 60, noise=0.05, seed=i)
+        gpu.scAddDescriptor(d)
+        orc.add_descriptor(d)
+        lid, yaw, m = gpu.detectLoopClosureID()
+        olid, oyaw, om = orc.detectLoopClosureID()
+        assert lid == olid and np.float32(yaw) == np.float32(oyaw), (i, lid, olid)
+        if i >= 30:
+            assert list(m.cand_idx) == om["cand_idx"], i
+            assert np.array_equal(np.array(m.cand_d2, np.float32).view(np.uint32), np.array(om["cand_d2"], np.float32).view(np.uint32))
+            assert m.nn_idx == om["nn_idx"] and m.nn_align == om["nn_align"]
+            assert np.float64(m.min_dist).view(np.uint64) == np.float64(om["min_dist"]).view(np.uint64)
+        loops += lid >= 0
+    assert gpu.scSize() == orc.size() == 340
+    assert loops >= 15
+    orc.close()
+
+
+def test_batched_distance_matches_oracle(gpu):
+    descs = make_descriptors(64, seed=9)
+    descs[40] = np.zeros((20, 60))                  # an empty descriptor: NaN similarity, never the minimum
+    descs[41] = revisit(descs[3], 17, 0.02, 1)
+    gpu.scReset()
+    for d in descs:
+        gpu.scAddDescriptor(d)
+    cand = np.arange(64, dtype=np.int32)
+    for q in (3, 41, 63):
+        dist, shift = gpu.distanceBtnScanContext(q, cand)
+        for c in range(64):
+            od, os_ = O.distance_btn_scancontext(descs[q], descs[c])
+            assert shift[c] == os_ and np.float64(dist[c]).view(np.uint64) == np.float64(od).view(np.uint64), (q, c)
+    d, s = gpu.distanceBtnScanContext(41, [3])
+    assert s[0] == 17 and d[0] < 0.01
+    with pytest.raises(s2m.S2MError):
+        gpu.distanceBtnScanContext(0, [64])
+    with pytest.raises(s2m.S2MError):
+        gpu.distanceBtnScanContext(64, [0])
+
+
+def test_add_scan_path_matches_oracle(gpu):
+    """makeAndSaveScancontextAndKeys on clouds: the device-built descriptors feed the detector like the oracle's."""
+    scene = synth.make_scene(seed=21, half=35.0, n_boxes=14)
+    rng = np.random.default_rng(2)
+    poses = [np.array([0, 0, 0.2 * k, 2.0 * np.cos(0.2 * k), 2.0 * np.sin(0.2 * k), 0.0]) for k in range(4)]
+    clouds = [synth.to_xyzi(synth.make_scan(scene, p, "velodyne64", 6000, seed=50 + k)) for k, p in enumerate(poses)]
+    gpu.scReset()
+    orc = O.SCManager()
+    found = 0
+    for k in range(36):                              # 36 key frames from 4 distinct sweeps (+ jitter)
+        c = clouds[k % 4].copy()
+        c[:, :3] += rng.normal(0, 0.01, (c.shape[0], 3)).astype(np.float32)
+        gpu.makeAndSaveScancontextAndKeys(c)
+        orc.add_scan(c)
+        lid, yaw, m = gpu.detectLoopClosureID()
+        olid, oyaw, om = orc.detectLoopClosureID()
+        assert lid == olid and np.float32(yaw) == np.float32(oyaw)
+        if k >= 30:
+            assert np.float64(m.min_dist).view(np.uint64) == np.float64(om["min_dist"]).view(np.uint64)
+            found += lid >= 0
+    assert found >= 1
+    orc.close()
