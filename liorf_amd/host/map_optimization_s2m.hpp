@@ -13,6 +13,7 @@
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/liorf_s2m.h"
@@ -174,6 +175,34 @@ private:
     void checkVoxel(int rc, const char* what) { if (rc != S2M_WARN_LEAF_TOO_SMALL) check(rc, what); }
     s2m_handle h_ = nullptr;
     bool scanResident_ = false;
+};
+
+// SCManager (reference include/Scancontext.h:56-113) on top of the same handle: the descriptor store and the
+// loop detector live on the device; method names and return values are the reference's.
+class SCManagerS2M {
+public:
+    explicit SCManagerS2M(s2m_handle h) : h_(h) {}
+    // void makeAndSaveScancontextAndKeys(pcl::PointCloud<SCPointType>& _scan_down) (Scancontext.cpp:236-250)
+    void makeAndSaveScancontextAndKeys(const std::vector<PointXYZI>& scan_down)
+    {
+        check(s2m_sc_add_scan(h_, scan_down.data(), scan_down.size(), sizeof(PointXYZI)), "s2m_sc_add_scan");
+    }
+    // std::pair<int, float> detectLoopClosureID(void) (Scancontext.cpp:253-344): {loop_id or -1, yaw_diff_rad}
+    std::pair<int, float> detectLoopClosureID()
+    {
+        int32_t id = -1; float yaw = 0.0f;
+        check(s2m_sc_detect_loop(h_, &id, &yaw, &lastMatch), "s2m_sc_detect_loop");
+        return { (int)id, yaw };
+    }
+    int size() const { return s2m_sc_size(h_); }
+    s2m_sc_match lastMatch{};
+
+private:
+    void check(int rc, const char* what)
+    {
+        if (rc != S2M_OK) throw std::runtime_error(std::string(what) + ": " + s2m_last_error(h_));
+    }
+    s2m_handle h_;
 };
 
 }  // namespace liorf_amd
