@@ -320,6 +320,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
         h->hctx.chunk_parts = h->chunk_parts.as<int32_t>();
         h->hctx.chunk_factor = h->chunk_factor.as<int32_t>();
         h->hctx.n_chunks = n_chunks;
+        h->hctx.density_pending = 1;
     }
     h->hctx.prevp = h->prevp.as<float4>();
     h->hctx.prior_valid = h->prior_valid.as<int32_t>();
@@ -373,7 +374,7 @@ void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* eve
         // both kernels take everything from the DevCtx block, so the captured graph stays valid from scan to scan
         hipLaunchKernelGGL(k_wave_density, dim3((nblocks * (kBlock / 64) + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
                            h->density_raw);
-        hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, dc, st);
+        hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, const_cast<DevCtx*>(dc), st);
     }
     for (int L = 0; L < n; L++) {
         if (events) (void)hipEventRecord(events[2 * L], h->stream);
@@ -412,6 +413,7 @@ int launch_loop(s2m_context* h)
             S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
             S2M_HIP(h, hipGraphLaunch(exec, h->stream));
             S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+            h->hctx.density_pending = 0;                  // cleared on the device by k_chunk_table_density: keep the host copy in step
             return S2M_OK;
         }
         h->use_graph = false;       // capture unsupported here: fall back to plain launches
@@ -421,6 +423,7 @@ int launch_loop(s2m_context* h)
     enqueue_loop(h, nblocks, dc, nullptr);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    h->hctx.density_pending = 0;
     return S2M_OK;
 }
 
@@ -774,8 +777,9 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
         if (h->density_raw > 0) {
             hipLaunchKernelGGL(k_wave_density, dim3((nblocks * (kBlock / 64) + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
                                h->density_raw);
-            hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, dc, st);
+            hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, const_cast<DevCtx*>(dc), st);
         }
+        h->hctx.density_pending = 0;                      // cleared on the device by the kernel: keep the host copy in step
         for (int L = 0; L < N; L++) {
             hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, (fuse && L >= 2) ? 1 : 0);
             if (!fuse || L == 0) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
@@ -856,6 +860,7 @@ static int time_iterations_impl(s2m_handle h, const float pose[6], int reps, flo
         S2M_HIP(h, hipMemsetAsync(h->plane_state.p, 0, sizeof(int32_t) * h->n_q, h->stream));
         if ((rc = push_state(h, pose))) return rc;
         enqueue_loop(h, h->hctx.nblocks, dc, h->iter_events.data());     // the real loop, launched one by one between event pairs
+        h->hctx.density_pending = 0;
         S2M_HIP(h, hipGetLastError());
         S2M_HIP(h, hipStreamSynchronize(h->stream));
         for (int it = 0; it < nit; it++) {

@@ -437,8 +437,11 @@ __global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict_
 }
 
 // per scan before launch 0, inside the captured loop: everything comes from the DevCtx block
-__global__ __launch_bounds__(1024) void k_chunk_table_density(const DevCtx* __restrict__ cp, DevState* __restrict__ st)
+__global__ __launch_bounds__(1024) void k_chunk_table_density(DevCtx* __restrict__ cp, DevState* __restrict__ st)
 {
+    if (!cp->density_pending) return;                     // once per scan (the flag is uniform: read before the barrier below)
+    __syncthreads();
+    if (threadIdx.x == 0) cp->density_pending = 0;
     chunk_table_body(cp->chunk_parts, cp->n_q, cp->n_chunks, cp->nblocks * (kBlock / 64), cp->wave_table_rw, cp->n_waves_rw,
                      cp->chunk_factor, st);
 }
@@ -1165,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_wave_density(const DevCtx* __restrict__
     const auto st = G(state);
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= st->n_waves) return;
+    if (!cp->density_pending || wv >= st->n_waves) return;   // the table of a scan is re-split once, at its first optimisation
     const auto tb = G((const int2*)cp->wave_table);
     const int2 e = make_int2(tb[wv].x, tb[wv].y);
     const int i = e.x + lane;

@@ -63,6 +63,7 @@ struct DevCtx {
     const int32_t* chunk_parts;   // [n_chunks] extent-based split wish per 64-point chunk
     int32_t* chunk_factor;        // [n_chunks] density-based extra split, zero between uses
     int32_t  n_chunks;
+    int32_t  density_pending;     // 1 from s2m_set_scan until the scan's first optimisation has re-split the table
     double* partials;             // [2][nblocks][kAcc], slot = launch parity
     DevState* state;
     s2m_iter_trace* trace;        // [kMaxIter]
