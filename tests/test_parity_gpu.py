@@ -325,3 +325,44 @@ def test_fused_and_plain_loop_agree(cfg_small, monkeypatch):
         assert np.array_equal(a[5], b[5])
         assert np.abs(a[3] - b[3]).max() <= 1e-6 and np.abs(a[4] - b[4]).max() <= 1e-6
     assert out[("0", 1)][0] < 30 and out[("0", 0)][0] == 30
+
+
+def test_two_handles_interleaved(cfg_tiny, cfg_small):
+    """Two handles (own stream, buffers, graph cache) used alternately give what each gives alone."""
+    ma, sa = synth.to_xyzi(cfg_tiny["map"]), synth.to_xyzi(cfg_tiny["scan"])
+    mb, sb = synth.to_xyzi(cfg_small["map"]), synth.to_xyzi(cfg_small["scan"])
+    solo = []
+    for m, s, p in ((ma, sa, cfg_tiny["pose_init"]), (mb, sb, cfg_small["pose_init"])):
+        g = s2m.MapOptimizationS2M()
+        g.setInputCloud(m)
+        solo.append(np.array(g.optimize(s, p).pose))
+        g.close()
+    ga, gb = s2m.MapOptimizationS2M(), s2m.MapOptimizationS2M()
+    ga.setInputCloud(ma)
+    gb.setInputCloud(mb)
+    for _ in range(3):
+        ga.setScan(sa); gb.setScan(sb)
+        ga.launch(cfg_tiny["pose_init"]); gb.launch(cfg_small["pose_init"])
+        ra, rb = ga.collect(), gb.collect()
+        assert np.abs(np.array(ra.pose) - solo[0]).max() <= 1e-6
+        assert np.abs(np.array(rb.pose) - solo[1]).max() <= 1e-6
+    ga.close(); gb.close()
+
+
+def test_density_resplit_changes_only_the_partition(cfg_small, monkeypatch):
+    """The density-aware re-split of the wave table (on by default) against the extent-only table."""
+    m, s = synth.to_xyzi(cfg_small["map"]), synth.to_xyzi(cfg_small["scan"])
+    res = {}
+    for raw in ("0", "40"):                       # 40 box points: nearly every wave is cut finer
+        monkeypatch.setenv("S2M_DENSITY_RAW", raw)
+        g = s2m.MapOptimizationS2M(early_exit=0)
+        g.setInputCloud(m)
+        r = g.optimize(s, cfg_small["pose_init"])
+        idx, d2, flag, coeff = g.surfOptimization(np.array(r.pose, np.float32))
+        res[raw] = (r.iters_run, r.n_sel_last, np.array(r.pose), idx, d2, flag, coeff)
+        g.close()
+    a, b = res["0"], res["40"]
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.abs(a[2] - b[2]).max() <= 1e-6
+    for k in (3, 5):
+        assert np.array_equal(a[k], b[k])
