@@ -2,7 +2,7 @@
 """Times the voxel-grid stages that feed the path on device-resident
 clouds, next to the CPU oracle on the same inputs.  Not the headline metric (bench.py is); prints one JSON line.
 
-  python tools/bench_voxel.py [--frames 50] [--frame-pts 30000] [--raw-pts 120000]
+  python tests/tools/bench_voxel.py [--frames 50] [--frame-pts 30000] [--raw-pts 120000]
 """
 import argparse
 import json
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

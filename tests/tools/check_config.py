@@ -1,7 +1,7 @@
 """Run one BASELINE config end to end on the GPU: registration result, per-launch kernel time,
 index build times; spot-check kNN exactness against the oracle's brute force on a sample."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from liorf_amd import s2m, synth
 from oracle import oracle as O
