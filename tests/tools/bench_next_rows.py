@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""Times the voxel-grid stages that feed the path on device-resident
-clouds, next to the CPU oracle on the same inputs.  Not the headline metric (bench.py is); prints one JSON line.
+"""Times the rows built from SURVEY.md section 8(f) - the voxel-grid stages that feed the path (F2 / F1, on
+device-resident clouds) and the ScanContext loop detector (F3) - next to the CPU oracle on the same inputs.
+Not the headline metric (bench.py is); prints one JSON line.
 
-  python tests/tools/bench_voxel.py [--frames 50] [--frame-pts 30000] [--raw-pts 120000]
+  python tests/tools/bench_next_rows.py [--frames 50] [--frame-pts 30000] [--raw-pts 120000] [--sc-keys 2000]
 """
 import argparse
 import json
@@ -20,6 +21,7 @@ def main():
     ap.add_argument("--frames", type=int, default=50)
     ap.add_argument("--frame-pts", type=int, default=30000)
     ap.add_argument("--raw-pts", type=int, default=120000)
+    ap.add_argument("--sc-keys", type=int, default=2000)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -71,6 +73,45 @@ def main():
         t2 = time.perf_counter()
         out["cpu_port"] = {"extractCloud_ms": round((t1 - t0) * 1e3, 2), "downsampleCurrentScan_ms": round((t2 - t1) * 1e3, 2), "cores": 1}
         out["parity"] = {"map_voxels_equal": bool(ref_map.shape[0] == n_map), "scan_voxels_equal": bool(ref_scan.shape[0] == n_scan)}
+    # ---- F3: ScanContext loop detector over a store of --sc-keys key frames ---------------------------------
+    nk = args.sc_keys
+    rng2 = np.random.default_rng(5)
+    descs = rng2.uniform(0.0, 6.0, (nk, 20, 60)) * (rng2.uniform(0, 1, (nk, 20, 60)) > 0.35)
+    descs[-1] = np.roll(descs[nk // 3], 23, axis=1)                # the newest key frame revisits an old place
+    eng.scReset()
+    for d in descs:
+        eng.scAddDescriptor(d)
+    eng.detectLoopClosureID()
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        lid, yaw, m = eng.detectLoopClosureID()
+    ms_detect = (time.perf_counter() - t0) / args.reps * 1e3
+    cand = np.arange(nk - 1, dtype=np.int32)
+    eng.distanceBtnScanContext(nk - 1, cand)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        dist, shift = eng.distanceBtnScanContext(nk - 1, cand)
+    ms_batch = (time.perf_counter() - t0) / args.reps * 1e3
+    out["scancontext"] = {"key_frames": nk, "detectLoopClosureID_ms": round(ms_detect, 3), "loop_id": lid,
+                          "distanceBtnScanContext_batch_ms": round(ms_batch, 3), "batch_pairs": int(len(cand)),
+                          "us_per_pair": round(ms_batch * 1e3 / len(cand), 3)}
+    if not args.no_cpu:
+        mgr = O.SCManager()
+        for d in descs:
+            mgr.add_descriptor(d)
+        mgr.detectLoopClosureID()
+        t0 = time.perf_counter()
+        olid, _, _ = mgr.detectLoopClosureID()
+        t1 = time.perf_counter()
+        sub = cand[:200]
+        for c in sub:
+            od, osh = O.distance_btn_scancontext(descs[nk - 1], descs[c])
+        t2 = time.perf_counter()
+        out["scancontext"]["cpu_port"] = {"detectLoopClosureID_ms": round((t1 - t0) * 1e3, 3),
+                                          "us_per_pair": round((t2 - t1) * 1e6 / len(sub), 2), "cores": 1,
+                                          "note": "ctypes call overhead included in us_per_pair"}
+        out["parity"]["sc_loop_id_equal"] = bool(olid == lid)
+        mgr.close()
     print(json.dumps(out))
     eng.close()
 
