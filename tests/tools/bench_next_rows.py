@@ -95,6 +95,20 @@ def main():
     out["scancontext"] = {"key_frames": nk, "detectLoopClosureID_ms": round(ms_detect, 3), "loop_id": lid,
                           "distanceBtnScanContext_batch_ms": round(ms_batch, 3), "batch_pairs": int(len(cand)),
                           "us_per_pair": round(ms_batch * 1e3 / len(cand), 3)}
+    # descriptor build (BASELINE config 5: ~300k-point dense scan), host cloud in, 20x60 + ring key out
+    big = np.zeros((300000, 8), np.float32)
+    big[:, :3] = rng2.uniform([-80, -80, -2], [80, 80, 10], (300000, 3)).astype(np.float32)
+    eng.makeScancontext(big)
+    t0 = time.perf_counter()
+    for _ in range(args.reps):
+        desc, key = eng.makeScancontext(big)
+    out["scancontext"]["makeScancontext_300k_ms"] = round((time.perf_counter() - t0) / args.reps * 1e3, 3)
+    out["scancontext"]["makeScancontext_note"] = "host cloud: includes the 9.6 MB pageable upload and the 9.8 KB readback"
+    if not args.no_cpu:
+        t0 = time.perf_counter()
+        odesc, okey = O.make_scancontext(big)
+        out["scancontext"]["makeScancontext_300k_cpu_ms"] = round((time.perf_counter() - t0) * 1e3, 3)
+        out["parity"]["sc_descriptor_equal"] = bool(np.array_equal(desc, odesc))
     if not args.no_cpu:
         mgr = O.SCManager()
         for d in descs:
