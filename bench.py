@@ -188,12 +188,15 @@ def main():
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        ncpu = os.cpu_count() or 1
+        # (b) of SURVEY section 8d: all the cores this job may use - a one-GPU box grants a 16-thread share of its host,
+        # whatever os.cpu_count() says (256 threads on 16 granted ones spin against each other: 8 it/s)
+        ncpu_all = os.cpu_count() or 1
+        ncpu = max(1, min(len(os.sched_getaffinity(0)), 16))
         b4 = cpu_baseline(cfg, args.cpu_iters, 4, args.cpu_scans)     # ~4 s wall, ~15 s of core time
         ball = cpu_baseline(cfg, args.cpu_iters, ncpu, 1)
         out["cpu_baseline"] = {
             "value": round(b4["iters_per_s"], 3), "unit": "LM iterations/s", "cores": 4, "kind": "port",
-            "host": {"cpu_model": cpu_model(), "nproc": ncpu},
+            "host": {"cpu_model": cpu_model(), "nproc": ncpu_all, "threads_granted": ncpu},
             "sample": f"{args.cpu_scans} registrations x {args.cpu_iters} LM iterations of the same {n_q}x{n_m} workload, oracle "
                       f"kd-tree back-end, OpenMP 4 threads (reference numberOfCores, config/kitti.yaml:63), "
                       f"median registration after one warm-up, {b4['seconds']:.1f} s wall in total; kd-tree build excluded; "
