@@ -678,11 +678,13 @@ int s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu, s
         r.n_sel_last = s.n_sel_last;
         h->persist_degenerate = s.isDegenerate;
         memcpy(h->persist_matP, s.matP, sizeof(s.matP));
-        // trace: executed iterations; a stalled loop repeats its single no-op record
-        int n_exec = s.iters_run;
+        // trace: executed iterations; a loop that stalled at iteration k (fewer than min_corr correspondences,
+        // pose unchanged, :1178-1180) repeats that no-op record for the iterations the reference would still run
+        int n_exec = s.iters_run, stall_at = -1;
         for (int i = 0; i < n_exec && i < kMaxIter; i++) {
-            if (s.stalled && i > 0) h->last_trace[i] = h->last_trace[0];
-            else h->last_trace[i] = h->h_trace[i];
+            if (stall_at >= 0) { h->last_trace[i] = h->last_trace[stall_at]; continue; }
+            h->last_trace[i] = h->h_trace[i];
+            if (s.stalled && !h->h_trace[i].stepped) stall_at = i;
         }
         h->last_trace_n = n_exec < kMaxIter ? n_exec : kMaxIter;
         host_transform_update(h->prm, imu, t, r.affine);                           // :1317
