@@ -381,11 +381,27 @@ __device__ __forceinline__ void chunk_table_body(const int32_t* __restrict__ par
                                                  int32_t* __restrict__ factor, DevState* __restrict__ st)
 {
     __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s, tot_s[3];
+    __shared__ int32_t carry_s, tot_s[3], base_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // One workgroup per CU runs measurably faster than two (steady launch 25 vs 27.7 us at 120k points): the
+    // density wishes are dropped if they alone would push the grid over one workgroup on each of the 256 CUs.
+    constexpr int kOnePerCu = 256 * (kBlock / 64);
+    bool use_factor = factor != nullptr;
+    if (use_factor) {
+        int tb = 0, tf = 0;
+        for (int c = threadIdx.x; c < n_chunks; c += 1024) { tb += min(8, parts[c]); tf += min(8, parts[c] * max(factor[c], 1)); }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { tb += __shfl_xor(tb, off, 64); tf += __shfl_xor(tf, off, 64); }
+        if (threadIdx.x == 0) { tot_s[0] = 0; base_s = 0; }
+        __syncthreads();
+        if (lane == 0) { atomicAdd(&base_s, tb); atomicAdd(&tot_s[0], tf); }
+        __syncthreads();
+        use_factor = !(base_s <= kOnePerCu && tot_s[0] > kOnePerCu);
+        __syncthreads();
+    }
     // pass A: total waves wished for when parts are capped at 8, 4, 2
     int t8 = 0, t4 = 0, t2 = 0;
-    auto wish = [&](int c) { return min(8, parts[c] * (factor ? max(factor[c], 1) : 1)); };
+    auto wish = [&](int c) { return min(8, parts[c] * (use_factor ? max(factor[c], 1) : 1)); };
     for (int c = threadIdx.x; c < n_chunks; c += 1024) { const int p = wish(c); t8 += p; t4 += min(p, 4); t2 += min(p, 2); }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { t8 += __shfl_xor(t8, off, 64); t4 += __shfl_xor(t4, off, 64); t2 += __shfl_xor(t2, off, 64); }
