@@ -366,3 +366,28 @@ def test_density_resplit_changes_only_the_partition(cfg_small, monkeypatch):
     assert np.abs(a[2] - b[2]).max() <= 1e-6
     for k in (3, 5):
         assert np.array_equal(a[k], b[k])
+
+
+def test_against_golden_fixture(gpu):
+    """The committed fixture (tests/golden/s2m_tiny_golden.npz) without the oracle in the loop."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s2m_tiny_golden.npz"))
+    gpu.setInputCloud(synth.to_xyzi(g["map"]))
+    gpu.setScan(synth.to_xyzi(g["scan"]))
+    idx, d2, flag, coeff = gpu.surfOptimization(g["pose_init"])
+    gated = g["idx5"][:, 0] >= 0
+    assert np.array_equal(idx[:, 0] >= 0, gated) and np.array_equal(idx[gated], g["idx5"][gated])
+    assert np.array_equal(d2[gated].view(np.uint32), g["d2_5"][gated].view(np.uint32))
+    assert np.array_equal(flag, g["flag"]) and np.array_equal(coeff.view(np.uint32), g["coeff"].view(np.uint32))
+    AtA, AtB, n = gpu.normal_eq(g["pose_init"])
+    assert n == int(g["n_sel"])
+    assert np.allclose(AtA, g["AtA"], rtol=1e-5, atol=1e-5 * np.abs(g["AtA"]).max())
+    gpu.transformTobeMapped = g["pose_init"].copy()
+    r = gpu.scan2MapOptimization()
+    assert r.iters_run == int(g["iters_run"])
+    assert np.abs(np.array(r.pose) - g["pose_final"]).max() <= 1e-5
+    tr = gpu.trace()
+    assert np.array_equal(np.array([t.n_sel for t in tr]), g["n_sel_iter"])
+    assert np.abs(np.array([t.delta[:] for t in tr]) - g["deltas"]).max() <= 1e-4
+    desc, key = gpu.makeScancontext(synth.to_xyzi(g["scan"]))
+    assert (desc != g["sc_desc"]).sum() <= 2

@@ -96,3 +96,24 @@ def test_transform_point_cloud_matches_matrix_form():
     assert np.array_equal(out[:, 4], rec[:, 4])
     T = O.getTransformation(np.r_[pose[3:], pose[:3]])
     assert np.array_equal(out[0, :3], (T[:, 0] * rec[0, 0] + T[:, 1] * rec[0, 1] + T[:, 2] * rec[0, 2] + T[:, 3]).astype(np.float32))
+
+
+def test_next_rows_golden_vectors():
+    """The committed fixture (tests/golden/make_golden_next_rows.py) pins the oracle's voxel grid, cloud
+    transform and ScanContext matching against regressions."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s2m_next_rows_golden.npz"))
+    vox, small = O.voxel_grid(g["vox_in"], float(g["vox_leaf"]))
+    assert not small and np.array_equal(vox.view(np.uint32), g["vox_out"].view(np.uint32))
+    xf = O.transform_point_cloud(g["xf_in"], g["xf_pose"])
+    fin = np.isfinite(g["xf_out"]).all(1)                               # the cloud carries a few non-finite points
+    assert np.array_equal(fin, np.isfinite(xf).all(1))
+    assert np.abs(xf[fin] - g["xf_out"][fin]).max() <= 2e-6             # libm sinf/cosf may differ in the last ulp
+    m = O.SCManager()
+    for k, d in enumerate(g["sc_descs"]):
+        m.add_descriptor(d.astype(np.float64))
+        lid, yaw, det = m.detectLoopClosureID()
+        assert lid == g["sc_loop_id"][k] and det["nn_idx"] == g["sc_nn_idx"][k] and det["nn_align"] == g["sc_nn_align"][k]
+        assert abs(det["min_dist"] - g["sc_min_dist"][k]) <= 1e-12 and abs(yaw - g["sc_yaw"][k]) <= 1e-7
+    assert g["sc_loop_id"][35] == 0 and g["sc_nn_align"][35] == 13
+    m.close()

@@ -188,3 +188,22 @@ def test_cpp_host_mirror_chain(gpu, tmp_path):
     assert ("iters %d " % ro.iters_run) in lines[1]
     got = np.array([float(v) for v in lines[2].split()[1:]], np.float32)
     assert np.abs(got - np.array(ro.pose)).max() <= 1e-4
+
+
+def test_next_rows_against_golden_fixture(gpu):
+    """The committed fixture (tests/golden/s2m_next_rows_golden.npz) without the oracle in the loop."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "s2m_next_rows_golden.npz"))
+    _same_records(gpu.voxelGrid(g["vox_in"], float(g["vox_leaf"])), g["vox_out"])
+    xf = gpu.transformPointCloud(g["xf_in"], g["xf_pose"])
+    fin = np.isfinite(g["xf_out"]).all(1)
+    assert np.abs(xf[fin] - g["xf_out"][fin]).max() <= 2e-6
+    gpu.scReset()
+    for k, d in enumerate(g["sc_descs"]):
+        gpu.scAddDescriptor(d.astype(np.float64))
+        lid, yaw, m = gpu.detectLoopClosureID()
+        assert lid == g["sc_loop_id"][k] and m.nn_idx == g["sc_nn_idx"][k] and m.nn_align == g["sc_nn_align"][k]
+        assert np.float64(m.min_dist).view(np.uint64) == np.float64(g["sc_min_dist"][k]).view(np.uint64)
+        assert np.float32(yaw) == g["sc_yaw"][k]
+    dist, shift = gpu.distanceBtnScanContext(35, np.arange(35))
+    assert np.array_equal(shift, g["sc_pair_shift"]) and np.array_equal(dist.view(np.uint64), g["sc_pair_dist"].view(np.uint64))
