@@ -258,6 +258,29 @@ int  s2m_sc_detect_loop(s2m_handle h, int32_t* loop_id, float* yaw_diff_rad, s2m
  * batched form in which this row is worth running on a GPU. */
 int  s2m_sc_distance(s2m_handle h, int32_t query_idx, const int32_t* cand_idx, int32_t m, double* dist, int32_t* shift);
 
+/* ---- ICP loop-closure alignment ------------------------------------------
+ * pcl::IterativeClosestPoint<PointType, PointType> as performRSLoopClosure / performSCLoopClosure configure
+ * and run it (reference src/mapOptmization.cpp:571-586, :663-678): setMaxCorrespondenceDistance,
+ * setMaximumIterations, setTransformationEpsilon, setEuclideanFitnessEpsilon, RANSAC off, identity guess,
+ * align(); then hasConverged(), getFitnessScore(), getFinalTransformation(). src = cureKeyframeCloud, tgt =
+ * prevKeyframeCloud (host records). T is the row-major 4x4 final transformation (source -> target). As in
+ * PCL, reaching max_iterations counts as converged; fewer than 3 correspondences does not. */
+typedef struct s2m_icp_params {
+    double  max_correspondence_distance;   /* historyKeyframeSearchRadius * 2 (:573)  */
+    int32_t max_iterations;                /* 100 (:574)                              */
+    double  transformation_epsilon;        /* 1e-6 (:575)                             */
+    double  euclidean_fitness_epsilon;     /* 1e-6 (:576)                             */
+} s2m_icp_params;
+typedef struct s2m_icp_result {
+    float   T[16];
+    int32_t converged;
+    int32_t iterations;
+    double  fitness_score;                 /* getFitnessScore(): mean squared nearest-neighbour distance after alignment */
+} s2m_icp_result;
+int  s2m_icp_default_params(s2m_icp_params* p);
+int  s2m_icp_align(s2m_handle h, const void* src, size_t n_src, const void* tgt, size_t n_tgt, size_t stride_bytes,
+                   const s2m_icp_params* p /* NULL = defaults */, s2m_icp_result* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,7 @@
 #include "s2m_host_math.hpp"
 #include "s2m_kernels.hpp"
 #include "s2m_voxel.hpp"
+#include "s2m_icp.hpp"
 
 using namespace s2m;
 
@@ -56,6 +57,8 @@ struct s2m_context {
     size_t sc_n = 0, sc_cap = 0, sc_n_search = 0;
     int    sc_counter = 0;             // tree_making_period_conter (include/Scancontext.cpp:270-283)
     VoxWorkspace* vox = nullptr;
+    IcpWorkspace* icp = nullptr;       // ICP loop-closure alignment (section 8(f) F4)
+    DevBuf icp_src, icp_tgt;           // staging of host clouds
 
     DevCtx hctx{};
     bool ctx_dirty = true;
@@ -581,6 +584,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (hipMemsetAsync(h->q_counts.p, 0, sizeof(int32_t) * kPolarCells, h->stream) != hipSuccess) return bail(S2M_ERR_HIP);
 
     if (!(h->vox = vox_create())) return bail(S2M_ERR_HIP);
+    if (!(h->icp = icp_create())) return bail(S2M_ERR_HIP);
 
     memset(&h->hctx, 0, sizeof(h->hctx));
     h->hctx.nblocks = kBlocksQuantum;
@@ -614,6 +618,9 @@ int s2m_destroy(s2m_handle h)
                        &h->sc_store_desc, &h->sc_store_ring, &h->sc_store_sector, &h->sc_cand, &h->sc_res };
     for (DevBuf* b : bufs) if (b->p) (void)hipFree(b->p);
     vox_destroy(h->vox);
+    icp_destroy(h->icp);
+    if (h->icp_src.p) (void)hipFree(h->icp_src.p);
+    if (h->icp_tgt.p) (void)hipFree(h->icp_tgt.p);
     if (h->h_state) (void)hipHostFree(h->h_state);
     if (h->h_trace) (void)hipHostFree(h->h_trace);
     if (h->h_mm) (void)hipHostFree(h->h_mm);
@@ -1030,6 +1037,45 @@ int s2m_transform_cloud(s2m_handle h, const void* pts, size_t n, size_t stride_b
     hipError_t e = vox_transform_frames(h->vox, h->stream, src, stride_bytes, offsets, T, 1, h->frames_xf.as<unsigned char>(), kDsStride);
     if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "cloud transform", e);
     return download_records(h, h->frames_xf, n, out, out_stride_bytes, n);
+}
+
+// ---- section 8(f) row F4: ICP loop-closure alignment -----------------------------------------------
+
+int s2m_icp_default_params(s2m_icp_params* p)
+{
+    if (!p) return S2M_ERR_INVALID_ARG;
+    p->max_correspondence_distance = 20.0;      // historyKeyframeSearchRadius (10, include/utility.h:245) * 2 (:573)
+    p->max_iterations = 100;                    // :574
+    p->transformation_epsilon = 1e-6;           // :575
+    p->euclidean_fitness_epsilon = 1e-6;        // :576
+    return S2M_OK;
+}
+
+int s2m_icp_align(s2m_handle h, const void* src, size_t n_src, const void* tgt, size_t n_tgt, size_t stride_bytes,
+                  const s2m_icp_params* p, s2m_icp_result* out)
+{
+    int rc = check_records(h, src, n_src, stride_bytes);
+    if (rc) return rc;
+    if ((rc = check_records(h, tgt, n_tgt, stride_bytes))) return rc;
+    if (!out) return S2M_ERR_INVALID_ARG;
+    s2m_icp_params prm;
+    if (p) prm = *p; else s2m_icp_default_params(&prm);
+    if (!(prm.max_correspondence_distance > 0.0) || prm.max_iterations < 1)
+        return fail(h, S2M_ERR_INVALID_ARG, "ICP needs a positive correspondence distance and at least one iteration");
+    S2M_HIP(h, hipSetDevice(h->device));
+    if (n_src) { if ((rc = ensure(h, h->icp_src, n_src * stride_bytes))) return rc;
+                 S2M_HIP(h, hipMemcpyAsync(h->icp_src.p, src, n_src * stride_bytes, hipMemcpyHostToDevice, h->stream)); }
+    if (n_tgt) { if ((rc = ensure(h, h->icp_tgt, n_tgt * stride_bytes))) return rc;
+                 S2M_HIP(h, hipMemcpyAsync(h->icp_tgt.p, tgt, n_tgt * stride_bytes, hipMemcpyHostToDevice, h->stream)); }
+    IcpParams ip{ prm.max_correspondence_distance, prm.max_iterations, prm.transformation_epsilon, prm.euclidean_fitness_epsilon };
+    IcpResult r;
+    hipError_t e = icp_align(h->icp, h->stream, h->icp_src.as<unsigned char>(), n_src, h->icp_tgt.as<unsigned char>(), n_tgt,
+                             stride_bytes, ip, &r);
+    if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "ICP alignment", e);
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    memcpy(out->T, r.T, sizeof(r.T));
+    out->converged = r.converged; out->iterations = r.iterations; out->fitness_score = r.fitness;
+    return S2M_OK;
 }
 
 int s2m_make_scancontext(s2m_handle h, const void* pts, size_t n, size_t stride_bytes,

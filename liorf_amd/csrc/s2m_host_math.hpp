@@ -3,6 +3,7 @@
 // the LMOptimization trig (:1170-1175) and transformUpdate() (:1323-1363).
 #pragma once
 #include <cmath>
+#include <utility>
 #include "s2m_types.h"
 
 namespace s2m {
@@ -91,6 +92,77 @@ inline void host_transform_update(const s2m_params& p, const s2m_imu_init* imu, 
     t[1] = constraint_transformation(t[1], p.rot_tol);
     t[5] = constraint_transformation(t[5], p.z_tol);
     host_pose_to_transform(t, affine, nullptr);
+}
+
+// Eigen::umeyama without scaling, as pcl::registration::TransformationEstimationSVD uses it (reference
+// src/mapOptmization.cpp:583 -> icp.align, PCL 1.10 [ext]): R = U S V^T of the cross-covariance sigma =
+// (1/n) sum (tgt - mean_tgt)(src - mean_src)^T with S(2) = -1 if det(U) det(V) < 0, t = mean_tgt - R mean_src.
+// The 3x3 SVD is a one-sided Jacobi in fp64 (Eigen: JacobiSVD<Matrix3f>); T is row-major 4x4.
+inline void host_svd3(const double A[9], double U[9], double S[3], double V[9])
+{
+    double W[9];
+    for (int i = 0; i < 9; i++) { W[i] = A[i]; V[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double a = 0, b = 0, c = 0;
+                for (int k = 0; k < 3; k++) { a += W[k * 3 + p] * W[k * 3 + p]; b += W[k * 3 + q] * W[k * 3 + q]; c += W[k * 3 + p] * W[k * 3 + q]; }
+                off += c * c;
+                if (std::fabs(c) <= 1e-300 || std::fabs(c) <= 1e-17 * std::sqrt(a * b)) continue;
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+                for (int k = 0; k < 3; k++) {
+                    const double wp = W[k * 3 + p], wq = W[k * 3 + q];
+                    W[k * 3 + p] = cs * wp - sn * wq; W[k * 3 + q] = sn * wp + cs * wq;
+                    const double vp = V[k * 3 + p], vq = V[k * 3 + q];
+                    V[k * 3 + p] = cs * vp - sn * vq; V[k * 3 + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off < 1e-300) break;
+    }
+    for (int j = 0; j < 3; j++) {
+        double nrm = 0;
+        for (int k = 0; k < 3; k++) nrm += W[k * 3 + j] * W[k * 3 + j];
+        S[j] = std::sqrt(nrm);
+    }
+    for (int i = 0; i < 2; i++)
+        for (int j = i + 1; j < 3; j++)
+            if (S[j] > S[i]) {
+                std::swap(S[i], S[j]);
+                for (int k = 0; k < 3; k++) { std::swap(W[k * 3 + i], W[k * 3 + j]); std::swap(V[k * 3 + i], V[k * 3 + j]); }
+            }
+    for (int j = 0; j < 3; j++)
+        for (int k = 0; k < 3; k++) U[k * 3 + j] = S[j] > 1e-300 ? W[k * 3 + j] / S[j] : 0.0;
+    if (S[2] <= 1e-12 * S[0]) {          // rank-deficient: complete U to an orthonormal basis
+        U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+inline double host_det3(const double M[9])
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+inline void host_umeyama(const float mean_src[3], const float mean_tgt[3], const float sigma[9], float T[16])
+{
+    double A[9], U[9], S[3], V[9];
+    for (int i = 0; i < 9; i++) A[i] = (double)sigma[i];
+    host_svd3(A, U, S, V);
+    const double sgn[3] = { 1.0, 1.0, (host_det3(U) * host_det3(V) < 0) ? -1.0 : 1.0 };
+    float R[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double a = 0;
+            for (int k = 0; k < 3; k++) a += U[i * 3 + k] * sgn[k] * V[j * 3 + k];
+            R[i * 3 + j] = (float)a;
+        }
+    for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = mean_tgt[i] - (R[i * 3 + 0] * mean_src[0] + R[i * 3 + 1] * mean_src[1] + R[i * 3 + 2] * mean_src[2]);
+    }
 }
 
 }  // namespace s2m

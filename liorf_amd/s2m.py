@@ -32,6 +32,7 @@ ABI_SYMBOLS = [
     "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
     "s2m_transform_cloud",
+    "s2m_icp_default_params", "s2m_icp_align",
     "s2m_sc_reset", "s2m_sc_size", "s2m_sc_add_scan", "s2m_sc_add_descriptor", "s2m_sc_detect_loop", "s2m_sc_distance",
 ]
 S2M_WARN_LEAF_TOO_SMALL = 1
@@ -65,6 +66,15 @@ class IterTrace(C.Structure):
 class ScMatch(C.Structure):
     _fields_ = [("min_dist", C.c_double), ("nn_idx", C.c_int32), ("nn_align", C.c_int32),
                 ("cand_idx", C.c_int32 * 3), ("cand_d2", C.c_float * 3)]
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_correspondence_distance", C.c_double), ("max_iterations", C.c_int32),
+                ("transformation_epsilon", C.c_double), ("euclidean_fitness_epsilon", C.c_double)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("T", C.c_float * 16), ("converged", C.c_int32), ("iterations", C.c_int32), ("fitness_score", C.c_double)]
 
 
 class S2MError(RuntimeError):
@@ -133,6 +143,8 @@ def load_library(path: str | None = None) -> C.CDLL:
                                     vp, C.c_size_t, C.c_size_t, szp]
     L.s2m_transform_cloud.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, vp, C.c_size_t]
     dp, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.s2m_icp_default_params.argtypes = [C.POINTER(IcpParams)]
+    L.s2m_icp_align.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.POINTER(IcpParams), C.POINTER(IcpResult)]
     L.s2m_sc_reset.argtypes = [vp]
     L.s2m_sc_size.argtypes = [vp]
     L.s2m_sc_add_scan.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
@@ -394,6 +406,21 @@ class MapOptimizationS2M:
         if n < 0:
             self._check(n, "s2m_debug_wave_profile")
         return out[:n]
+
+    # -- ICP loop-closure alignment (reference src/mapOptmization.cpp:571-586), SURVEY.md section 8(f) row F4 --
+    def icpAlign(self, cureKeyframeCloud, prevKeyframeCloud, **params):
+        """icp.setInputSource(cure); icp.setInputTarget(prev); icp.align(): (T 4x4, hasConverged, getFitnessScore, iterations)."""
+        a, na, st = _records(cureKeyframeCloud)
+        b, nb, st2 = _records(prevKeyframeCloud)
+        if st != st2:
+            raise ValueError("both clouds must share one record stride")
+        p = IcpParams()
+        self.lib.s2m_icp_default_params(C.byref(p))
+        for k, v in params.items():
+            setattr(p, k, v)
+        r = IcpResult()
+        self._check(self.lib.s2m_icp_align(self.h, a.ctypes.data, na, b.ctypes.data, nb, st, C.byref(p), C.byref(r)), "s2m_icp_align")
+        return np.array(r.T, np.float32).reshape(4, 4), bool(r.converged), r.fitness_score, r.iterations
 
     # -- SCManager (reference include/Scancontext.cpp), SURVEY.md section 8(f) row F3 --------------
     def scReset(self):

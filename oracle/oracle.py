@@ -112,6 +112,9 @@ def lib() -> C.CDLL:
         L.orc_sc_add_scan.argtypes = [vp, vp, C.c_size_t, C.c_size_t]
         L.orc_sc_detectLoopClosureID.argtypes = [vp, fp, dp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                                  C.POINTER(C.c_int * 3), C.POINTER(C.c_float * 3)]
+        L.orc_icp_align.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_double, C.c_int, C.c_double, C.c_double, C.c_int,
+                                    fp, C.POINTER(C.c_int), dp, C.POINTER(C.c_int)]
+        L.orc_icp_umeyama.argtypes = [fp, fp, fp, fp]
         L.orc_voxelGrid.argtypes = [vp, C.c_size_t, C.c_size_t, C.c_float, vp, C.c_size_t, C.c_size_t,
                                     C.POINTER(C.c_size_t)]
         L.orc_transformPointCloud.argtypes = [vp, C.c_size_t, C.c_size_t, fp, vp, C.c_size_t]
@@ -350,6 +353,26 @@ class SCManager:
         ci, cd = (C.c_int * 3)(), (C.c_float * 3)()
         lid = lib().orc_sc_detectLoopClosureID(self.h, C.byref(yaw), C.byref(md), C.byref(ni), C.byref(na), C.byref(ci), C.byref(cd))
         return lid, yaw.value, dict(min_dist=md.value, nn_idx=ni.value, nn_align=na.value, cand_idx=list(ci), cand_d2=list(cd))
+
+
+def icp_align(src, tgt, max_corr_dist=30.0, max_iter=100, trans_eps=1e-6, fit_eps=1e-6, num_threads=8):
+    """pcl::IterativeClosestPoint as configured at reference src/mapOptmization.cpp:571-586:
+    (T 4x4 float32, converged, fitness score, iterations)."""
+    a, na, st = _records(src)
+    b, nb, st2 = _records(tgt)
+    assert st == st2
+    T = np.zeros((4, 4), np.float32)
+    conv, its, fit = C.c_int(0), C.c_int(0), C.c_double(0)
+    lib().orc_icp_align(a.ctypes.data, na, b.ctypes.data, nb, st, max_corr_dist, max_iter, trans_eps, fit_eps, num_threads,
+                        _fp(T), C.byref(conv), C.byref(fit), C.byref(its))
+    return T, bool(conv.value), fit.value, its.value
+
+
+def icp_umeyama(mean_src, mean_tgt, sigma):
+    T = np.zeros((4, 4), np.float32)
+    lib().orc_icp_umeyama(_fp(np.ascontiguousarray(mean_src, np.float32)), _fp(np.ascontiguousarray(mean_tgt, np.float32)),
+                          _fp(np.ascontiguousarray(sigma, np.float32)), _fp(T))
+    return T
 
 
 def voxel_grid(pts, leaf: float):

@@ -1186,3 +1186,189 @@ int orc_sc_detectLoopClosureID(orc_sc* m, float* yaw_diff_rad, double* min_dist_
     *min_dist_out = min_dist; *nn_idx_out = nn_idx; *nn_align_out = nn_align;
     return loop_id;
 }
+
+/* ==== section 8(f) row F4: ICP loop-closure alignment (src/mapOptmization.cpp:571-586, :663-678) ========
+ * pcl::IterativeClosestPoint<PointXYZI, PointXYZI> (Scalar = float) with the settings of the call site:
+ * max correspondence distance 2 * historyKeyframeSearchRadius, 100 iterations, transformation epsilon 1e-6,
+ * Euclidean fitness epsilon 1e-6, no RANSAC, identity guess.  PCL is not vendored: restated from PCL 1.10
+ * [ext] - registration/impl/icp.hpp (computeTransformation), correspondence_estimation.hpp
+ * (determineCorrespondences: nearest target point, kept if d2 <= max_dist^2),
+ * transformation_estimation_svd.hpp -> Eigen::umeyama without scaling (mean, demeaned cross-covariance / n,
+ * SVD, R = U S V^T with S(2) = -1 if det(U) det(V) < 0, t = mean_tgt - R mean_src),
+ * default_convergence_criteria.hpp (hasConverged, state machine as published), and Registration::
+ * getFitnessScore.  Restatement choices where PCL delegates: the nearest neighbour is brute force with
+ * ties to the lower index (PCL: FLANN kd-tree); the 3x3 SVD is a fp64 one-sided Jacobi (Eigen:
+ * JacobiSVD<Matrix3f>); means and covariance are summed left to right in fp32 as Eigen would in a scalar
+ * build.  Differences against a PCL build are of the order of fp32 rounding of those sums.
+ */
+static void icp_svd3(const double A[9], double U[9], double S[3], double V[9])
+{
+    /* one-sided Jacobi on the columns of W = A (row-major 3x3): W V = U S */
+    double W[9]; memcpy(W, A, sizeof(W));
+    for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < 2; p++)
+            for (int q = p + 1; q < 3; q++) {
+                double a = 0, b = 0, c = 0;
+                for (int k = 0; k < 3; k++) { a += W[k * 3 + p] * W[k * 3 + p]; b += W[k * 3 + q] * W[k * 3 + q]; c += W[k * 3 + p] * W[k * 3 + q]; }
+                off += c * c;
+                if (fabs(c) <= 1e-300 || fabs(c) <= 1e-17 * sqrt(a * b)) continue;
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int k = 0; k < 3; k++) {
+                    const double wp = W[k * 3 + p], wq = W[k * 3 + q];
+                    W[k * 3 + p] = cs * wp - sn * wq; W[k * 3 + q] = sn * wp + cs * wq;
+                    const double vp = V[k * 3 + p], vq = V[k * 3 + q];
+                    V[k * 3 + p] = cs * vp - sn * vq; V[k * 3 + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off < 1e-300) break;
+    }
+    for (int j = 0; j < 3; j++) {
+        double nrm = 0; for (int k = 0; k < 3; k++) nrm += W[k * 3 + j] * W[k * 3 + j];
+        S[j] = sqrt(nrm);
+    }
+    /* sort descending (like Eigen), permuting the columns of W and V */
+    for (int i = 0; i < 2; i++) for (int j = i + 1; j < 3; j++) if (S[j] > S[i]) {
+        double ts = S[i]; S[i] = S[j]; S[j] = ts;
+        for (int k = 0; k < 3; k++) { double t1 = W[k * 3 + i]; W[k * 3 + i] = W[k * 3 + j]; W[k * 3 + j] = t1; double t2 = V[k * 3 + i]; V[k * 3 + i] = V[k * 3 + j]; V[k * 3 + j] = t2; }
+    }
+    for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) U[k * 3 + j] = S[j] > 1e-300 ? W[k * 3 + j] / S[j] : 0.0;
+    /* complete a rank-deficient U to an orthonormal basis (cross products) */
+    if (S[2] <= 1e-12 * S[0]) {
+        U[2] = U[3] * U[7] - U[6] * U[4]; U[5] = U[6] * U[1] - U[0] * U[7]; U[8] = U[0] * U[4] - U[3] * U[1];
+    }
+}
+
+static double det3(const double M[9])
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+/* rigid transform (row-major 4x4, float) from the sums of one iteration; shared with nothing on the GPU side */
+void orc_icp_umeyama(const float mean_src[3], const float mean_tgt[3], const float sigma[9] /* (1/n) sum tgt_d src_d^T */, float T[16])
+{
+    double A[9], U[9], S[3], V[9];
+    for (int i = 0; i < 9; i++) A[i] = (double)sigma[i];
+    icp_svd3(A, U, S, V);
+    double sgn[3] = { 1.0, 1.0, (det3(U) * det3(V) < 0) ? -1.0 : 1.0 };
+    float R[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double a = 0; for (int k = 0; k < 3; k++) a += U[i * 3 + k] * sgn[k] * V[j * 3 + k];
+        R[i * 3 + j] = (float)a;
+    }
+    for (int i = 0; i < 16; i++) T[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) T[i * 4 + j] = R[i * 3 + j];
+        T[i * 4 + 3] = mean_tgt[i] - (R[i * 3 + 0] * mean_src[0] + R[i * 3 + 1] * mean_src[1] + R[i * 3 + 2] * mean_src[2]);
+    }
+}
+
+int orc_icp_align(const void* src, size_t n_src, const void* tgt, size_t n_tgt, size_t stride_bytes,
+                  double max_corr_dist, int max_iter, double trans_eps, double fit_eps, int num_threads,
+                  float T_final[16], int* converged, double* fitness, int* iterations)
+{
+    const unsigned char* sb = (const unsigned char*)src; const unsigned char* tb = (const unsigned char*)tgt;
+    float* cur = (float*)malloc(sizeof(float) * 3 * (n_src ? n_src : 1));       /* input_transformed */
+    float* tg = (float*)malloc(sizeof(float) * 3 * (n_tgt ? n_tgt : 1));
+    int32_t* ci = (int32_t*)malloc(sizeof(int32_t) * (n_src ? n_src : 1));
+    float* cd = (float*)malloc(sizeof(float) * (n_src ? n_src : 1));
+    for (size_t i = 0; i < n_src; i++) memcpy(cur + 3 * i, sb + i * stride_bytes, 12);
+    for (size_t i = 0; i < n_tgt; i++) memcpy(tg + 3 * i, tb + i * stride_bytes, 12);
+    for (int i = 0; i < 16; i++) T_final[i] = (i % 5 == 0) ? 1.0f : 0.0f;
+    const double max_d2 = max_corr_dist * max_corr_dist;
+    const double rot_thr = 1.0 - trans_eps, trl_thr = trans_eps, mse_abs = 1e-12, mse_rel = fit_eps;
+    double prev_mse = DBL_MAX;
+    int it = 0, conv = 0, similar = 0;
+    const int max_similar = 0;                                          /* max_iterations_similar_transforms_ */
+    if (num_threads < 1) num_threads = 1;
+    for (;;) {
+        /* determineCorrespondences */
+        #pragma omp parallel for num_threads(num_threads) schedule(static)
+        for (long i = 0; i < (long)n_src; i++) {
+            const float* p = cur + 3 * i;
+            float best = INFINITY; int32_t bi = -1;
+            if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))
+                for (size_t j = 0; j < n_tgt; j++) {
+                    const float dx = p[0] - tg[3 * j], dy = p[1] - tg[3 * j + 1], dz = p[2] - tg[3 * j + 2];
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 < best) { best = d2; bi = (int32_t)j; }
+                }
+            if (bi >= 0 && (double)best <= max_d2) { ci[i] = bi; cd[i] = best; } else ci[i] = -1;
+        }
+        size_t cnt = 0;
+        for (size_t i = 0; i < n_src; i++) cnt += ci[i] >= 0;
+        if (cnt < 3) { conv = 0; break; }                               /* min_number_correspondences_ */
+        /* estimateRigidTransformation: umeyama */
+        float ms[3] = { 0, 0, 0 }, mt[3] = { 0, 0, 0 };
+        for (size_t i = 0; i < n_src; i++) if (ci[i] >= 0)
+            for (int d = 0; d < 3; d++) { ms[d] += cur[3 * i + d]; mt[d] += tg[3 * (size_t)ci[i] + d]; }
+        for (int d = 0; d < 3; d++) { ms[d] /= (float)cnt; mt[d] /= (float)cnt; }
+        float sg[9] = { 0 };
+        double mse = 0.0;
+        for (size_t i = 0; i < n_src; i++) if (ci[i] >= 0) {
+            float a[3], b[3];
+            for (int d = 0; d < 3; d++) { a[d] = cur[3 * i + d] - ms[d]; b[d] = tg[3 * (size_t)ci[i] + d] - mt[d]; }
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) sg[r * 3 + c] += b[r] * a[c];
+            mse += (double)cd[i];
+        }
+        for (int k = 0; k < 9; k++) sg[k] /= (float)cnt;
+        mse /= (double)cnt;
+        float T[16];
+        orc_icp_umeyama(ms, mt, sg, T);
+        /* transformCloud (input_transformed in place) and final = T * final */
+        for (size_t i = 0; i < n_src; i++) {
+            const float x = cur[3 * i], y = cur[3 * i + 1], z = cur[3 * i + 2];
+            cur[3 * i]     = T[0] * x + T[1] * y + T[2]  * z + T[3];
+            cur[3 * i + 1] = T[4] * x + T[5] * y + T[6]  * z + T[7];
+            cur[3 * i + 2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+        }
+        float F[16];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) {
+            float a = 0; for (int k = 0; k < 4; k++) a += T[r * 4 + k] * T_final[k * 4 + c];
+            F[r * 4 + c] = a;
+        }
+        memcpy(T_final, F, sizeof(F));
+        ++it;
+        /* DefaultConvergenceCriteria::hasConverged */
+        int is_similar = 0;
+        if (it >= max_iter) { conv = 1; break; }                        /* CONVERGENCE_CRITERIA_ITERATIONS */
+        const double cos_angle = 0.5 * ((double)T[0] + (double)T[5] + (double)T[10] - 1.0);
+        const double tsq = (double)T[3] * T[3] + (double)T[7] * T[7] + (double)T[11] * T[11];
+        if (cos_angle >= rot_thr && tsq <= trl_thr) { if (similar >= max_similar) { conv = 1; break; } is_similar = 1; }   /* TRANSFORM */
+        if (fabs(mse - prev_mse) < mse_abs) { if (similar >= max_similar) { conv = 1; break; } is_similar = 1; }            /* ABS_MSE */
+        if (fabs(mse - prev_mse) / prev_mse < mse_rel) { if (similar >= max_similar) { conv = 1; break; } is_similar = 1; }   /* REL_MSE */
+        similar = is_similar ? similar + 1 : 0;
+        prev_mse = mse;
+    }
+    /* getFitnessScore(): mean squared distance of the aligned source to its nearest target points */
+    double fs = 0.0; size_t nr = 0;
+    {
+        float* a = (float*)malloc(sizeof(float) * 3 * (n_src ? n_src : 1));
+        for (size_t i = 0; i < n_src; i++) {
+            float p[3]; memcpy(p, sb + i * stride_bytes, 12);
+            a[3 * i]     = T_final[0] * p[0] + T_final[1] * p[1] + T_final[2]  * p[2] + T_final[3];
+            a[3 * i + 1] = T_final[4] * p[0] + T_final[5] * p[1] + T_final[6]  * p[2] + T_final[7];
+            a[3 * i + 2] = T_final[8] * p[0] + T_final[9] * p[1] + T_final[10] * p[2] + T_final[11];
+        }
+        #pragma omp parallel for num_threads(num_threads) schedule(static)
+        for (long i = 0; i < (long)n_src; i++) {
+            const float* p = a + 3 * i;
+            float best = INFINITY;
+            if (isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))
+                for (size_t j = 0; j < n_tgt; j++) {
+                    const float dx = p[0] - tg[3 * j], dy = p[1] - tg[3 * j + 1], dz = p[2] - tg[3 * j + 2];
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 < best) best = d2;
+                }
+            cd[i] = best;
+        }
+        for (size_t i = 0; i < n_src; i++) if (cd[i] < INFINITY) { fs += (double)cd[i]; nr++; }
+        free(a);
+    }
+    *converged = conv; *iterations = it; *fitness = nr ? fs / (double)nr : DBL_MAX;
+    free(cur); free(tg); free(ci); free(cd);
+    return 0;
+}

@@ -136,6 +136,12 @@ void     orc_sc_add_scan(orc_sc* m, const void* pts, size_t n, size_t stride_byt
 int      orc_sc_detectLoopClosureID(orc_sc* m, float* yaw_diff_rad, double* min_dist, int* nn_idx, int* nn_align,
                                     int cand_idx[3], float cand_d2[3]);
 
+/* section 8(f) row F4: pcl::IterativeClosestPoint as configured at src/mapOptmization.cpp:571-586 [ext PCL 1.10] */
+void     orc_icp_umeyama(const float mean_src[3], const float mean_tgt[3], const float sigma[9], float T[16]);
+int      orc_icp_align(const void* src, size_t n_src, const void* tgt, size_t n_tgt, size_t stride_bytes,
+                       double max_corr_dist, int max_iter, double trans_eps, double fit_eps, int num_threads,
+                       float T_final[16], int* converged, double* fitness, int* iterations);
+
 #ifdef __cplusplus
 }
 #endif
