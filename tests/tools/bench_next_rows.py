@@ -126,6 +126,23 @@ def main():
                                           "note": "ctypes call overhead included in us_per_pair"}
         out["parity"]["sc_loop_id_equal"] = bool(olid == lid)
         mgr.close()
+    # ---- F4: ICP loop-closure alignment, a key-frame cloud against a 25-key-frame submap ----------------------
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from test_icp_cpu import icp_scene
+    src_i, tgt_i, T_true = icp_scene(n_tgt=30000, n_src=5000, seed=4)
+    eng.icpAlign(src_i, tgt_i, max_correspondence_distance=30.0)
+    t0 = time.perf_counter()
+    Ti, convi, fiti, itsi = eng.icpAlign(src_i, tgt_i, max_correspondence_distance=30.0)
+    ms_icp = (time.perf_counter() - t0) * 1e3
+    out["icp"] = {"source_points": 5000, "target_points": 30000, "iterations": itsi, "converged": convi, "align_ms": round(ms_icp, 3),
+                  "ms_per_iteration": round(ms_icp / max(itsi + 1, 1), 4), "fitness": fiti,
+                  "translation_error_m": float(np.abs(Ti[:3, 3] - T_true[:3, 3]).max())}
+    if not args.no_cpu:
+        t0 = time.perf_counter()
+        To, convo, fito, itso = O.icp_align(src_i, tgt_i, max_corr_dist=30.0, num_threads=4)
+        out["icp"]["cpu_port"] = {"align_ms": round((time.perf_counter() - t0) * 1e3, 1), "iterations": itso, "cores": 4,
+                                  "note": "brute-force nearest neighbour (PCL would use a kd-tree)"}
+        out["parity"]["icp_T_max_abs_diff"] = float(np.abs(Ti - To).max())
     print(json.dumps(out))
     eng.close()
 
