@@ -164,6 +164,25 @@ public:
         }
     }
 
+    // The ICP block of performRSLoopClosure / performSCLoopClosure (:571-586, :663-678): settings, align(),
+    // hasConverged(), getFitnessScore(), getFinalTransformation().  Returns false where the reference returns early.
+    float historyKeyframeSearchRadius = 10.0f;        // include/utility.h:245
+    float historyKeyframeFitnessScore = 0.3f;         // include/utility.h:248
+    bool icpAlign(const std::vector<PointXYZI>& cureKeyframeCloud, const std::vector<PointXYZI>& prevKeyframeCloud,
+                  float finalTransformation[16])
+    {
+        if (cureKeyframeCloud.size() < 300 || prevKeyframeCloud.size() < 1000) return false;       // :565-566
+        s2m_icp_params p;
+        s2m_icp_default_params(&p);
+        p.max_correspondence_distance = historyKeyframeSearchRadius * 2;                            // :573
+        s2m_icp_result r;
+        check(s2m_icp_align(h_, cureKeyframeCloud.data(), cureKeyframeCloud.size(), prevKeyframeCloud.data(),
+                            prevKeyframeCloud.size(), sizeof(PointXYZI), &p, &r), "s2m_icp_align");
+        if (!r.converged || r.fitness_score > historyKeyframeFitnessScore) return false;            // :585-586
+        std::memcpy(finalTransformation, r.T, sizeof(r.T));
+        return true;
+    }
+
     s2m_handle handle() const { return h_; }
 
 private:

@@ -117,3 +117,6 @@ def test_next_rows_golden_vectors():
         assert abs(det["min_dist"] - g["sc_min_dist"][k]) <= 1e-12 and abs(yaw - g["sc_yaw"][k]) <= 1e-7
     assert g["sc_loop_id"][35] == 0 and g["sc_nn_align"][35] == 13
     m.close()
+    T, conv, fit, its = O.icp_align(synth.to_xyzi(g["icp_src"]), synth.to_xyzi(g["icp_tgt"]), max_corr_dist=30.0)
+    assert conv == bool(g["icp_converged"]) and its == int(g["icp_iterations"])
+    assert np.abs(T - g["icp_T"]).max() <= 1e-6 and abs(fit - float(g["icp_fitness"])) <= 1e-9

@@ -207,3 +207,6 @@ def test_next_rows_against_golden_fixture(gpu):
         assert np.float32(yaw) == g["sc_yaw"][k]
     dist, shift = gpu.distanceBtnScanContext(35, np.arange(35))
     assert np.array_equal(shift, g["sc_pair_shift"]) and np.array_equal(dist.view(np.uint64), g["sc_pair_dist"].view(np.uint64))
+    T, conv, fit, its = gpu.icpAlign(synth.to_xyzi(g["icp_src"]), synth.to_xyzi(g["icp_tgt"]), max_correspondence_distance=30.0)
+    assert conv == bool(g["icp_converged"]) and abs(its - int(g["icp_iterations"])) <= 1
+    assert np.abs(T - g["icp_T"]).max() <= 2e-4 and abs(fit - float(g["icp_fitness"])) <= 1e-5
