@@ -15,8 +15,13 @@ orc = O.Oracle(knn_backend=0, num_threads=8); orc.set_map(m); orc.set_scan(s)
 r = gpu.optimize(s, p0)
 ro = O.Oracle(knn_backend=1, num_threads=8); ro.set_map(m); ro.set_scan(s); rr = ro.scan2MapOptimization(p0)
 tg, to = gpu.trace(), ro.trace()
+np.set_printoptions(precision=3, linewidth=200)
+print('both traces: gpu iters', r.iters_run, 'oracle iters', rr.iters_run)
+for k in range(max(len(tg), len(to))):
+    print(' it', k, 'gpu', (tg[k].n_sel, np.array(tg[k].delta[:]), tg[k].deltaR, tg[k].deltaT) if k < len(tg) else None)
+    print('      orc', (to[k].n_sel, np.array(to[k].delta[:]), to[k].deltaR, to[k].deltaT) if k < len(to) else None)
 pose = np.array(p0, np.float32)
-for k in range(len(to)):
+for k in range(min(len(to), len(tg))):
     idx, d2, flag, coeff = gpu.surfOptimization(pose)
     oidx, od2, oflag, ocoeff = orc.surfOptimization(pose)
     AtA, AtB, n = gpu.normal_eq(pose)
