@@ -8,7 +8,14 @@
 #pragma once
 #include <float.h>
 #include <math.h>
+#include <string.h>
 #include "s2m_types.h"
+
+#if defined(__HIPCC__)
+#define S2M_HD __host__ __device__
+#else
+#define S2M_HD
+#endif
 
 namespace s2m {
 
@@ -41,6 +48,63 @@ __device__ __forceinline__ void swap_if(bool c, float& a, float& b)
 __device__ __forceinline__ void swap_if(bool c, int& a, int& b)
 {
     int t = a; a = c ? b : a; b = c ? t : b;
+}
+
+// ------------------------------------------------------------------------------------------
+// sinf / cosf as glibc >= 2.28 computes them (sysdeps/ieee754/flt-32/s_sinf.c, s_cosf.c, s_sincosf.h;
+// S. Nagy's implementation [ext]): the reference builds its transform with std::sin/std::cos of floats
+// (pcl::getTransformation, :348-351, and the LM trig, :1170-1175), i.e. with the host's libm, and glibc's
+// sinf is not correctly rounded - near 0.3 rad it is one ulp off the correctly rounded value for 3 % of
+// the arguments.  One ulp in the transform is enough to flip a marginal correspondence, so the launches
+// that rebuild the transform on the device use the same arithmetic: argument reduction by a scaled
+// float-to-int conversion, degree-7 / degree-8 polynomials in fp64, one rounding to fp32 at the end.
+// Checked against glibc 2.35's sinf/cosf on 2e7 random arguments in [-4, 4]: no mismatch, with or without
+// FMA contraction of the polynomial; tests/test_parity_gpu.py::test_device_sincos_is_the_hosts compares the
+// device results with the test host's libm.  |x| >= 120 does not occur for a pose angle and takes the fp64
+// library function.
+// ------------------------------------------------------------------------------------------
+struct SincosfTable { double sign[4]; double hpi_inv, hpi, c0, c1, c2, c3, c4, s1, s2, s3; };
+S2M_HD inline const SincosfTable& sincosf_table(int negate)
+{
+    static constexpr SincosfTable T[2] = {
+        { { 1.0, -1.0, -1.0, 1.0 }, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, 0x1p0, -0x1.ffffffd0c621cp-2, 0x1.55553e1068f19p-5,
+          -0x1.6c087e89a359dp-10, 0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13 },
+        { { 1.0, -1.0, -1.0, 1.0 }, 0x1.45F306DC9C883p+23, 0x1.921FB54442D18p0, -0x1p0, 0x1.ffffffd0c621cp-2, -0x1.55553e1068f19p-5,
+          0x1.6c087e89a359dp-10, -0x1.99343027bf8c3p-16, -0x1.555545995a603p-3, 0x1.1107605230bc4p-7, -0x1.994eb3774cf24p-13 } };
+    return T[negate];
+}
+S2M_HD inline uint32_t abstop12(float x)
+{
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return (u >> 20) & 0x7ffu;
+}
+S2M_HD inline float sinf_poly(double x, double x2, const SincosfTable& p, int n)
+{
+    if ((n & 1) == 0) {
+        const double x3 = x * x2, s1 = p.s2 + x2 * p.s3, x7 = x3 * x2, s = x + x3 * p.s1;
+        return (float)(s + x7 * s1);
+    }
+    const double x4 = x2 * x2, c2 = p.c3 + x2 * p.c4, c1 = p.c0 + x2 * p.c1, x6 = x4 * x2, c = c1 + x4 * p.c2;
+    return (float)(c + x6 * c2);
+}
+// which = 0: sinf(y), 1: cosf(y)
+S2M_HD inline float glibc_sincosf(float y, int which)
+{
+    double x = (double)y;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {                      // |y| < pi/4
+        if (abstop12(y) < abstop12(0x1p-12f)) return which ? 1.0f : y;
+        return sinf_poly(x, x * x, sincosf_table(0), which);
+    }
+    if (abstop12(y) < abstop12(120.0f)) {
+        const SincosfTable& p0 = sincosf_table(0);
+        const double r = x * p0.hpi_inv;                                // reduce_fast: quadrant in bits 24..31
+        const int n = ((int32_t)r + 0x800000) >> 24;
+        x = x - (double)n * p0.hpi;
+        const double sgn = p0.sign[n & 3];
+        return sinf_poly(x * sgn, x * x, sincosf_table((n & 2) ? 1 : 0), n ^ which);
+    }
+    return which ? (float)cos(x) : (float)sin(x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1284,7 +1348,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
 
     // transPointAssociateToMap (:1069-1072) and the LM trig (:1170-1175). Launch 0 of a scan gets them
     // from the host (libm); later launches rebuild them from the pose: lanes 0..2 take one angle each
-    // (fp64 sincos rounded once to fp32).  With solve_prev the pose is first advanced by closing
+    // (glibc's sinf / cosf arithmetic, see glibc_sincosf).  With solve_prev the pose is first advanced by closing
     // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.
     float T[12], sc6[6];
     if (!solve_prev && st->T_valid) {
@@ -1310,9 +1374,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
             for (int k = 0; k < 6; k++) pose[k] = st->pose2[launch & 1][k];
         }
         const float ang = (lane == 0) ? pose[2] : ((lane == 1) ? pose[1] : pose[0]);   // lane 0: yaw, 1: pitch, 2+: roll
-        double sn, cs;
-        sincos((double)ang, &sn, &cs);
-        const float snf = (float)sn, csf = (float)cs;
+        const float snf = glibc_sincosf(ang, 0), csf = glibc_sincosf(ang, 1);      // what the host's libm would return
         const float B = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 0)), A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 0));
         const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 1)), C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 1));
         const float F = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 2)), E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 2));
@@ -1881,6 +1943,13 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
     __shared__ float s_out[8];
     float pose[6];
     lm_close_iteration<kFinThreads, true>(cp, st, nb_act, iter, true, mode == 1, pose0, degen0, sh, s_out, pose);
+}
+
+// Observation hook: the device's sinf / cosf of n arguments (tests compare them with the host's libm).
+__global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ x, int n, float* __restrict__ s, float* __restrict__ c)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { s[i] = glibc_sincosf(x[i], 0); c[i] = glibc_sincosf(x[i], 1); }
 }
 
 // Parameter blocks travel as kernel arguments (copied at launch), so the host never has to

@@ -391,3 +391,26 @@ def test_against_golden_fixture(gpu):
     assert np.abs(np.array([t.delta[:] for t in tr]) - g["deltas"]).max() <= 1e-4
     desc, key = gpu.makeScancontext(synth.to_xyzi(g["scan"]))
     assert (desc != g["sc_desc"]).sum() <= 2
+
+
+def test_device_sincos_is_the_hosts(gpu):
+    """The transform between LM iterations is rebuilt on the device with glibc's sinf / cosf arithmetic: the results
+    have to be the test host's libm results bit for bit (a correctly rounded sine differs from glibc's for ~3 % of
+    the arguments near 0.3 rad, and one ulp in the transform can flip a marginal correspondence)."""
+    import ctypes as C
+    libm = C.CDLL("libm.so.6")
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-3.2, 3.2, 400000), rng.uniform(0.25, 0.35, 200000), rng.uniform(-0.05, 0.05, 200000),
+                        rng.uniform(-1e-4, 1e-4, 1000), [0.0, -0.0, 0.30007112, 0.7853981, 0.7853982, 3.1415927, -3.1415927, 100.0]]).astype(np.float32)
+    sn, cs = gpu.deviceSincos(x)
+    ref_s, ref_c = np.empty_like(x), np.empty_like(x)
+    libm.sinf.restype = C.c_float; libm.sinf.argtypes = [C.c_float]
+    libm.cosf.restype = C.c_float; libm.cosf.argtypes = [C.c_float]
+    for i, v in enumerate(x[::8].tolist() + x[-8:].tolist()):          # 100k scalar libm calls
+        ref_s[i], ref_c[i] = libm.sinf(v), libm.cosf(v)
+    k = len(x[::8]) + 8
+    got_s = np.concatenate([sn[::8], sn[-8:]]); got_c = np.concatenate([cs[::8], cs[-8:]])
+    assert np.array_equal(got_s.view(np.uint32), ref_s[:k].view(np.uint32))
+    assert np.array_equal(got_c.view(np.uint32), ref_c[:k].view(np.uint32))
+    cr = np.sin(x.astype(np.float64)).astype(np.float32)
+    assert (cr != sn).mean() > 0.005                                   # glibc's sinf is not the correctly rounded one
