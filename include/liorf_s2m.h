@@ -159,10 +159,10 @@ int  s2m_surf_optimization(s2m_handle h, const float pose[6],
 /* matAtA / matAtB / laserCloudSelNum of one iteration at `pose` (:1182-1239). */
 int  s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6],
                    int32_t* n_sel);
-/* Observation hook: sinf / cosf of n host floats as the device computes them when it rebuilds the transform
- * between LM iterations (the arithmetic of glibc's sinf / cosf, so that the transform is the one the
- * reference's host libm would give). */
-int  s2m_debug_device_sincos(s2m_handle h, const float* x, size_t n, float* s, float* c);
+/* Observation hook: sinf / cosf (and atanf when `a` is not NULL) of n host floats as the device computes them -
+ * sin/cos when it rebuilds the transform between LM iterations, atan in the ScanContext sector angle. They follow
+ * the arithmetic of glibc's sinf / cosf / atanf, so that the device gives what the reference's host libm gives. */
+int  s2m_debug_device_trig(s2m_handle h, const float* x, size_t n, float* s, float* c, float* a);
 /* Raw device time (ms) of the last s2m_optimize* call, measured with HIP events
  * on the handle's stream; and of the last s2m_set_map / s2m_set_scan index build. */
 int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float* set_scan_ms);

@@ -807,19 +807,21 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
     return (int)n;
 }
 
-int s2m_debug_device_sincos(s2m_handle h, const float* x, size_t n, float* s, float* c)
+int s2m_debug_device_trig(s2m_handle h, const float* x, size_t n, float* s, float* c, float* a)
 {
     if (!h || (n > 0 && (!x || !s || !c)) || n > (size_t)0x3fffffff) return S2M_ERR_INVALID_ARG;
     if (n == 0) return S2M_OK;
     S2M_HIP(h, hipSetDevice(h->device));
-    int rc = ensure(h, h->vox_in, sizeof(float) * 3 * n);
+    int rc = ensure(h, h->vox_in, sizeof(float) * 4 * n);
     if (rc) return rc;
     float* d = h->vox_in.as<float>();
     S2M_HIP(h, hipMemcpyAsync(d, x, sizeof(float) * n, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_debug_sincos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float*)d, (int)n, d + n, d + 2 * n);
+    hipLaunchKernelGGL(k_debug_sincos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const float*)d, (int)n, d + n, d + 2 * n,
+                       a ? d + 3 * n : (float*)nullptr);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipMemcpyAsync(s, d + n, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipMemcpyAsync(c, d + 2 * n, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    if (a) S2M_HIP(h, hipMemcpyAsync(a, d + 3 * n, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
     return S2M_OK;
 }

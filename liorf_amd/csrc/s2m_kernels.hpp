@@ -59,7 +59,7 @@ __device__ __forceinline__ void swap_if(bool c, int& a, int& b)
 // that rebuild the transform on the device use the same arithmetic: argument reduction by a scaled
 // float-to-int conversion, degree-7 / degree-8 polynomials in fp64, one rounding to fp32 at the end.
 // Checked against glibc 2.35's sinf/cosf on 2e7 random arguments in [-4, 4]: no mismatch, with or without
-// FMA contraction of the polynomial; tests/test_parity_gpu.py::test_device_sincos_is_the_hosts compares the
+// FMA contraction of the polynomial; tests/test_parity_gpu.py::test_device_trig_is_the_hosts compares the
 // device results with the test host's libm.  |x| >= 120 does not occur for a pose angle and takes the fp64
 // library function.
 // ------------------------------------------------------------------------------------------
@@ -105,6 +105,46 @@ S2M_HD inline float glibc_sincosf(float y, int which)
         return sinf_poly(x * sgn, x * x, sincosf_table((n & 2) ? 1 : 0), n ^ which);
     }
     return which ? (float)cos(x) : (float)sin(x);
+}
+
+// atanf as glibc computes it (sysdeps/ieee754/flt-32/s_atanf.c: the fdlibm algorithm in fp32 [ext]; no FMA
+// variant exists for it): SCManager's xy2theta (include/Scancontext.cpp:23-36) calls atan on a float, i.e. the
+// host's atanf, and a sector index is the ceiling of the angle - one ulp decides on which side of a sector
+// boundary a point falls.  Checked against glibc 2.35's atanf on 2e7 random arguments: no mismatch; the
+// GPU tests compare whole descriptors with the oracle, which calls the host's libm.
+S2M_HD inline float glibc_atanf(float x)
+{
+    const float atanhi[4] = { 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f };
+    const float atanlo[4] = { 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f };
+    const float aT[11] = { 3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                           6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f };
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const int32_t hx = (int32_t)u, ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {                              // |x| >= 2^25
+        if (ix > 0x7f800000) return x + x;               // NaN
+        return (hx > 0) ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {                               // |x| < 0.4375
+        if (ix < 0x31000000) return x;                   // |x| < 2^-29
+        id = -1;
+    } else {
+        x = fabsf(x);
+        if (ix < 0x3f980000) {                           // |x| < 1.1875
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }
+            else                 { id = 1; x = (x - 1.0f) / (x + 1.0f); }
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }
+            else                 { id = 3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return (hx < 0) ? -r : r;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1946,10 +1986,11 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
 }
 
 // Observation hook: the device's sinf / cosf of n arguments (tests compare them with the host's libm).
-__global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ x, int n, float* __restrict__ s, float* __restrict__ c)
+__global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ x, int n, float* __restrict__ s, float* __restrict__ c,
+                                                      float* __restrict__ a)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { s[i] = glibc_sincosf(x[i], 0); c[i] = glibc_sincosf(x[i], 1); }
+    if (i < n) { s[i] = glibc_sincosf(x[i], 0); c[i] = glibc_sincosf(x[i], 1); if (a) a[i] = glibc_atanf(x[i]); }
 }
 
 // Parameter blocks travel as kernel arguments (copied at launch), so the host never has to
@@ -1979,10 +2020,10 @@ __global__ __launch_bounds__(256) void k_sc_polar_max(const unsigned char* __res
         const float z = (float)((double)p[2] + 2.0);                       // LIDAR_HEIGHT (:168)
         const float rng = sqrtf(x * x + y * y);                            // :171
         float th;                                                          // xy2theta (:23-36)
-        if ((x >= 0) & (y >= 0))      th = (float)(kdeg * (double)atanf(y / x));
-        else if ((x < 0) & (y >= 0))  th = (float)(180.0 - (kdeg * (double)atanf(y / (-x))));
-        else if ((x < 0) & (y < 0))   th = (float)(180.0 + (kdeg * (double)atanf(y / x)));
-        else if ((x >= 0) & (y < 0))  th = (float)(360.0 - (kdeg * (double)atanf((-y) / x)));
+        if ((x >= 0) & (y >= 0))      th = (float)(kdeg * (double)glibc_atanf(y / x));
+        else if ((x < 0) & (y >= 0))  th = (float)(180.0 - (kdeg * (double)glibc_atanf(y / (-x))));
+        else if ((x < 0) & (y < 0))   th = (float)(180.0 + (kdeg * (double)glibc_atanf(y / x)));
+        else if ((x >= 0) & (y < 0))  th = (float)(360.0 - (kdeg * (double)glibc_atanf((-y) / x)));
         else th = NAN;
         if ((double)rng > 80.0) continue;                                  // PC_MAX_RADIUS (:175)
         if (!(z == z)) continue;                                           // NaN z never wins desc < z

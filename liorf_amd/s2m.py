@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
     "s2m_transform_cloud",
-    "s2m_icp_default_params", "s2m_icp_align", "s2m_debug_device_sincos",
+    "s2m_icp_default_params", "s2m_icp_align", "s2m_debug_device_trig",
     "s2m_sc_reset", "s2m_sc_size", "s2m_sc_add_scan", "s2m_sc_add_descriptor", "s2m_sc_detect_loop", "s2m_sc_distance",
 ]
 S2M_WARN_LEAF_TOO_SMALL = 1
@@ -143,7 +143,7 @@ def load_library(path: str | None = None) -> C.CDLL:
                                     vp, C.c_size_t, C.c_size_t, szp]
     L.s2m_transform_cloud.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, vp, C.c_size_t]
     dp, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
-    L.s2m_debug_device_sincos.argtypes = [vp, fp, C.c_size_t, fp, fp]
+    L.s2m_debug_device_trig.argtypes = [vp, fp, C.c_size_t, fp, fp, fp]
     L.s2m_icp_default_params.argtypes = [C.POINTER(IcpParams)]
     L.s2m_icp_align.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.POINTER(IcpParams), C.POINTER(IcpResult)]
     L.s2m_sc_reset.argtypes = [vp]
@@ -379,12 +379,12 @@ class MapOptimizationS2M:
         self._check(self.lib.s2m_normal_eq(self.h, _fp(p), _fp(AtA), _fp(AtB), C.byref(n)), "s2m_normal_eq")
         return AtA, AtB, n.value
 
-    def deviceSincos(self, x):
-        """Observation hook: (sinf, cosf) of the float32 array x as the device computes them."""
+    def deviceTrig(self, x):
+        """Observation hook: (sinf, cosf, atanf) of the float32 array x as the device computes them."""
         a = np.ascontiguousarray(x, np.float32)
-        sn, cs = np.zeros_like(a), np.zeros_like(a)
-        self._check(self.lib.s2m_debug_device_sincos(self.h, _fp(a), a.size, _fp(sn), _fp(cs)), "s2m_debug_device_sincos")
-        return sn, cs
+        sn, cs, at = np.zeros_like(a), np.zeros_like(a), np.zeros_like(a)
+        self._check(self.lib.s2m_debug_device_trig(self.h, _fp(a), a.size, _fp(sn), _fp(cs), _fp(at)), "s2m_debug_device_trig")
+        return sn, cs, at
 
     def timing(self):
         a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
