@@ -513,7 +513,12 @@ __device__ __forceinline__ void chunk_table_body(const int32_t* __restrict__ par
     __syncthreads();
     if (lane == 0) { atomicAdd(&tot_s[0], t8); atomicAdd(&tot_s[1], t4); atomicAdd(&tot_s[2], t2); }
     __syncthreads();
-    const int pcap = (tot_s[0] <= capacity) ? 8 : ((tot_s[1] <= capacity) ? 4 : ((tot_s[2] <= capacity) ? 2 : 1));
+    // The grid holds at most two 8-wave workgroups per CU at once (512 workgroups = 4096 waves); a few waves
+    // beyond that cost a whole extra round.  A scan whose unsplit chunks still fit gives up splits before it
+    // gives up that (262 144 points = 4096 chunks exactly: 20.5k -> 22.2k LM iterations/s).
+    constexpr int kTwoPerCu = 2 * kOnePerCu;
+    const int cap_eff = (n_chunks <= kTwoPerCu) ? min(capacity, kTwoPerCu) : capacity;
+    const int pcap = (tot_s[0] <= cap_eff) ? 8 : ((tot_s[1] <= cap_eff) ? 4 : ((tot_s[2] <= cap_eff) ? 2 : 1));
     // pass B: scan and emit
     for (int base = 0; base < n_chunks; base += 1024) {
         const int c = base + threadIdx.x;
