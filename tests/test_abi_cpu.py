@@ -85,3 +85,26 @@ def test_cpp_host_harness_builds_and_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     out = subprocess.run([exe, "m.bin", "s.bin", "0", "0", "0", "0", "0", "0"], capture_output=True, text=True)
     assert out.returncode == 1 and "no CPU fallback" in out.stderr
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench_line.json is what `python bench.py` printed on the MI355X: one JSON object with the
+    driver's keys plus the `roofline` and `cpu_baseline` objects."""
+    import json
+    line = open(os.path.join(ROOT, "profiles", "r01_bench_line.json")).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] == 4 and c["unit"] == d["unit"]
+    # value is whole-job throughput: iterations of all steps over the timed wall clock
+    assert abs(d["value"] - d["config"]["lm_iters_per_step"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
