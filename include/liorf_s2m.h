@@ -82,7 +82,7 @@ typedef struct s2m_params {
  * accepted wherever this struct is taken and means imuAvailable = 0.
  */
 typedef struct s2m_imu_init {
-    int64_t imuAvailable;     /* cloud_info.imuAvailable */
+    int64_t imuAvailable;     /* cloud_info.imuAvailable; the path tests `imuAvailable == true` (:1325), i.e. == 1 */
     float   imuRollInit;      /* cloud_info.imuRollInit  */
     float   imuPitchInit;     /* cloud_info.imuPitchInit */
     float   imuYawInit;       /* cloud_info.imuYawInit (not read on this path) */
@@ -114,6 +114,12 @@ int  s2m_default_params(s2m_params* p);
 int  s2m_create(const s2m_params* p, s2m_handle* out);
 int  s2m_destroy(s2m_handle h);
 const char* s2m_last_error(s2m_handle h);       /* valid until the next call on h */
+/* The reference reads its ParamServer members (z_tollerance, rotation_tollerance, imuType, imuRPYWeight,
+ * include/utility.h:211-233) every time the path runs; a caller that changes them after s2m_create applies the new
+ * values here. Everything except device_id, stream, k_neighbors and gate_sq (fixed at creation: the search grid is
+ * built for the gate) may change between scans; takes effect with the next s2m_optimize* call. */
+int  s2m_set_params(s2m_handle h, const s2m_params* p);
+int  s2m_get_params(s2m_handle h, s2m_params* out);
 
 /* ---- inputs ------------------------------------------------------------- */
 /* Replaces kdtreeSurfFromMap->setInputCloud(laserCloudSurfFromMapDS) (:1302):

@@ -80,7 +80,7 @@ struct s2m_context {
     bool use_graph = true;
     bool fuse_solve = true;            // env S2M_NO_FUSE=1 keeps one k_finalize per iteration (A/B measurements)
     int  fuse_max_blocks = 0;          // largest grid that closes iterations inside k_register (env S2M_FUSE_MAX overrides)
-    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_up = nullptr;
     float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
     int base_parts = 1;
     int density_raw = 320;             // box points above which a wave asks for a finer cut (env S2M_DENSITY_RAW, 0 = off)
@@ -176,10 +176,7 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
     if (rc) return rc;
     S2M_HIP(h, hipSetDevice(h->device));
     S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
-    h->n_m = n;
-    h->hctx.n_m = (int32_t)n;
-    h->ctx_dirty = true;
-    if (n == 0) { h->t_set_map_ms = 0; return upload_ctx(h); }
+    if (n == 0) { h->n_m = 0; h->hctx.n_m = 0; h->ctx_dirty = true; h->t_set_map_ms = 0; return upload_ctx(h); }
 
     const unsigned char* d_pts;
     if (on_device) d_pts = static_cast<const unsigned char*>(pts);
@@ -231,6 +228,8 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
 
     if (h->have_scan && h->n_q > 0 && h->prior_valid.p)      // neighbours of the old map are meaningless now
         S2M_HIP(h, hipMemsetAsync(h->prior_valid.p, 0, sizeof(int32_t) * h->n_q, h->stream));
+    h->n_m = n;                                       // committed only now: a failure above leaves the old index in place
+    h->hctx.n_m = (int32_t)n;
     h->hctx.g = g;
     h->hctx.map_sorted = h->map_sorted.as<float4>();
     h->hctx.cell_start = h->m_cell_start.as<int32_t>();
@@ -271,6 +270,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     else {
         if ((rc = ensure(h, h->raw_scan, n * stride))) return rc;
         S2M_HIP(h, hipMemcpyAsync(h->raw_scan.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
+        S2M_HIP(h, hipEventRecord(h->ev_up, h->stream));   // waited for below: the caller's buffer is free when this call returns
         d_pts = h->raw_scan.as<unsigned char>();
     }
     // locality order of the scan: log-polar Z-order bins (k_polar_count), no host round trip
@@ -332,7 +332,11 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     h->ctx_dirty = true;
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
     h->scan_timing_pending = true;
-    return upload_ctx(h);     // asynchronous; a device-resident source must outlive the next synchronising call
+    if ((rc = upload_ctx(h))) return rc;
+    // A host source (pageable or pinned) has been copied by the time this returns; the ordering kernels behind the copy
+    // keep running.  A device-resident source is read asynchronously and must outlive the next synchronising call.
+    if (!on_device) S2M_HIP(h, hipEventSynchronize(h->ev_up));
+    return S2M_OK;
 }
 
 void fill_state(s2m_context* h, DevState* s, const float pose[6])
@@ -428,6 +432,17 @@ int launch_loop(s2m_context* h)
     S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
     h->hctx.density_pending = 0;
     return S2M_OK;
+}
+
+// the parameters the kernels read, into the host copy of the DevCtx block
+void params_to_ctx(s2m_context* h, const s2m_params& prm)
+{
+    h->hctx.gate_f = nextafterf((float)prm.gate_sq, INFINITY);
+    h->hctx.gate_sq = prm.gate_sq; h->hctx.plane_tol = prm.plane_tol; h->hctx.weight_scale = prm.weight_scale;
+    h->hctx.weight_min = prm.weight_min; h->hctx.conv_deg = prm.conv_deg; h->hctx.conv_cm = prm.conv_cm;
+    h->hctx.eig_thresh = prm.eig_thresh; h->hctx.min_corr = prm.min_corr; h->hctx.max_iter = prm.max_iter;
+    h->hctx.early_exit = prm.early_exit;
+    h->ctx_dirty = true;
 }
 
 constexpr size_t kDsStride = 32;       // filtered clouds are kept as pcl::PointXYZI records
@@ -570,7 +585,8 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
         h->own_stream = true;
     }
     if (hipEventCreate(&h->ev_a) != hipSuccess || hipEventCreate(&h->ev_b) != hipSuccess ||
-        hipEventCreate(&h->ev_c) != hipSuccess || hipEventCreate(&h->ev_d) != hipSuccess) return bail(S2M_ERR_HIP);
+        hipEventCreate(&h->ev_c) != hipSuccess || hipEventCreate(&h->ev_d) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess) return bail(S2M_ERR_HIP);
     if (hipHostMalloc((void**)&h->h_state, sizeof(DevState) * 2) != hipSuccess) return bail(S2M_ERR_HIP);
     if (hipHostMalloc((void**)&h->h_trace, sizeof(s2m_iter_trace) * kMaxIter) != hipSuccess) return bail(S2M_ERR_HIP);
     if (hipHostMalloc((void**)&h->h_mm, 64) != hipSuccess) return bail(S2M_ERR_HIP);
@@ -591,11 +607,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->hctx.partials = h->partials.as<double>();
     h->hctx.state = h->state.as<DevState>();
     h->hctx.trace = h->trace.as<s2m_iter_trace>();
-    h->hctx.gate_f = nextafterf((float)prm.gate_sq, INFINITY);
-    h->hctx.gate_sq = prm.gate_sq; h->hctx.plane_tol = prm.plane_tol; h->hctx.weight_scale = prm.weight_scale;
-    h->hctx.weight_min = prm.weight_min; h->hctx.conv_deg = prm.conv_deg; h->hctx.conv_cm = prm.conv_cm;
-    h->hctx.eig_thresh = prm.eig_thresh; h->hctx.min_corr = prm.min_corr; h->hctx.max_iter = prm.max_iter;
-    h->hctx.early_exit = prm.early_exit;
+    params_to_ctx(h, prm);
     if (const char* e = getenv("S2M_ABLATE")) h->hctx.ablate = atoi(e);
     h->ctx_dirty = true;
     if (upload_ctx(h) != S2M_OK) return bail(S2M_ERR_HIP);
@@ -629,12 +641,40 @@ int s2m_destroy(s2m_handle h)
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
     if (h->ev_c) (void)hipEventDestroy(h->ev_c);
     if (h->ev_d) (void)hipEventDestroy(h->ev_d);
+    if (h->ev_up) (void)hipEventDestroy(h->ev_up);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return S2M_OK;
 }
 
 const char* s2m_last_error(s2m_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int s2m_get_params(s2m_handle h, s2m_params* out)
+{
+    if (!h || !out) return S2M_ERR_INVALID_ARG;
+    *out = h->prm;
+    return S2M_OK;
+}
+
+int s2m_set_params(s2m_handle h, const s2m_params* p)
+{
+    if (!h || !p) return S2M_ERR_INVALID_ARG;
+    if (p->struct_size != sizeof(s2m_params)) return fail(h, S2M_ERR_INVALID_ARG, "s2m_params.struct_size does not match this library");
+    if (p->device_id != h->prm.device_id || p->stream != h->prm.stream || p->k_neighbors != h->prm.k_neighbors ||
+        p->gate_sq != h->prm.gate_sq)
+        return fail(h, S2M_ERR_INVALID_ARG, "device_id, stream, k_neighbors and gate_sq are fixed at s2m_create (the search grid is built for the gate)");
+    if (p->max_iter < 1 || p->max_iter > kMaxIter) return fail(h, S2M_ERR_INVALID_ARG, "max_iter out of range");
+    if (h->opt_pending) return fail(h, S2M_ERR_INVALID_ARG, "an optimize launch is pending: collect it first");
+    if (p->max_iter != h->prm.max_iter) {               // the captured loops hold max_iter launches
+        S2M_HIP(h, hipSetDevice(h->device));
+        S2M_HIP(h, hipStreamSynchronize(h->stream));
+        for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+        h->graphs.clear();
+    }
+    h->prm = *p;
+    params_to_ctx(h, h->prm);                           // uploaded by the next call that launches anything
+    return S2M_OK;
+}
 
 int s2m_set_map(s2m_handle h, const void* pts, size_t n, size_t stride_bytes)
 { return set_map_impl(h, pts, n, stride_bytes, false); }

@@ -78,8 +78,8 @@ inline float constraint_transformation(float value, float limit)      // :1355-1
 // transformUpdate (:1323-1353): optional IMU roll/pitch slerp, clamps, affine of the result.
 inline void host_transform_update(const s2m_params& p, const s2m_imu_init* imu, float t[6], float affine[12])
 {
-    if (imu && imu->imuAvailable && p.imu_type) {
-        if (std::fabs(imu->imuPitchInit) < 1.4f) {
+    if (imu && imu->imuAvailable == 1 && p.imu_type) {                 // `cloudInfo.imuAvailable == true` (:1325): int64 == 1
+        if ((double)std::fabs(imu->imuPitchInit) < 1.4) {               // std::abs(float) < 1.4 (:1327): compared as doubles
             const double w = (double)p.imu_rpy_weight;
             double r, pi, y;
             quat_to_rpy(quat_slerp(quat_from_rpy(t[0], 0, 0), quat_from_rpy(imu->imuRollInit, 0, 0), w), r, pi, y);

@@ -74,9 +74,7 @@ public:
         s2m_default_params(&p);
         p.device_id = device_id;
         p.stream = hip_stream;
-        p.imu_type = imuType; p.imu_rpy_weight = imuRPYWeight;
-        p.z_tol = z_tollerance; p.rot_tol = rotation_tollerance;
-        const int rc = s2m_create(&p, &h_);
+        const int rc = s2m_create(&p, &h_);       // the ParamServer members below are pushed before every call (pushParams)
         if (rc != S2M_OK)
             throw std::runtime_error("s2m_create failed (" + std::to_string(rc) + "): no gfx950 device; there is no CPU fallback");
     }
@@ -140,9 +138,23 @@ public:
         haveKeyPoses = !cloudKeyPoses6D.empty();
     }
 
+    // The reference reads imuType / imuRPYWeight / z_tollerance / rotation_tollerance (ParamServer members, set from
+    // the yaml after construction) whenever transformUpdate() runs (:1325-1350): the current member values are
+    // handed to the library before every registration.
+    void pushParams()
+    {
+        s2m_params p;
+        check(s2m_get_params(h_, &p), "s2m_get_params");
+        if (p.imu_type == imuType && p.imu_rpy_weight == imuRPYWeight && p.z_tol == z_tollerance && p.rot_tol == rotation_tollerance) return;
+        p.imu_type = imuType; p.imu_rpy_weight = imuRPYWeight;
+        p.z_tol = z_tollerance; p.rot_tol = rotation_tollerance;
+        check(s2m_set_params(h_, &p), "s2m_set_params");
+    }
+
     // void scan2MapOptimization() (:1295-1321)
     void scan2MapOptimization()
     {
+        pushParams();
         s2m_imu_init imu;
         imu.imuAvailable = cloudInfo.imuAvailable;
         imu.imuRollInit = cloudInfo.imuRollInit; imu.imuPitchInit = cloudInfo.imuPitchInit; imu.imuYawInit = cloudInfo.imuYawInit;

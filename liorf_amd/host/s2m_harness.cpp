@@ -2,7 +2,9 @@
 // PointXYZI records (32-byte stride, the reference's wire layout) and an initial guess, runs
 // scan2MapOptimization() through the host mirror, prints the result.  Fails loudly without a GPU.
 //
-//   s2m_harness map.bin scan.bin roll pitch yaw x y z
+//   s2m_harness map.bin scan.bin roll pitch yaw x y z [imuType imuRPYWeight z_tollerance rotation_tollerance imuAvailable imuRollInit imuPitchInit]
+//       the optional tail sets the ParamServer members AFTER the node is constructed (as the reference's yaml
+//       loading does) and the cloud_info IMU fields transformUpdate() reads (:1325-1350)
 //   s2m_harness --chain frames.bin frames.txt raw_scan.bin map_leaf scan_leaf roll pitch yaw x y z
 //       the handler's three steps in order: extractCloud() over the key frames listed in frames.txt (one line
 //       "n_points x y z roll pitch yaw" per frame, clouds back to back in frames.bin), downsampleCurrentScan(),
@@ -31,6 +33,9 @@ static void print_result(const liorf_amd::MapOptimizationS2M& node)
     std::printf("skipped %d iters %d converged %d degenerate %d n_sel %d\n", r.skipped, r.iters_run, r.converged, r.is_degenerate, r.n_sel_last);
     std::printf("transformTobeMapped %.9g %.9g %.9g %.9g %.9g %.9g\n", node.transformTobeMapped[0], node.transformTobeMapped[1],
                 node.transformTobeMapped[2], node.transformTobeMapped[3], node.transformTobeMapped[4], node.transformTobeMapped[5]);
+    std::printf("incrementalOdometryAffineBack");
+    for (int k = 0; k < 12; k++) std::printf(" %.9g", node.incrementalOdometryAffineBack[k]);
+    std::printf("\n");
 }
 
 static int run_chain(char** argv)
@@ -67,12 +72,24 @@ int main(int argc, char** argv)
     try {
         if (argc == 2 && std::string(argv[1]) == "--version") { std::puts(s2m_version()); return 0; }
         if (argc == 13 && std::string(argv[1]) == "--chain") return run_chain(argv);
-        if (argc != 9) { std::fprintf(stderr, "usage: %s map.bin scan.bin roll pitch yaw x y z\n", argv[0]); return 2; }
+        if (argc != 9 && argc != 16) {
+            std::fprintf(stderr, "usage: %s map.bin scan.bin roll pitch yaw x y z [imuType imuRPYWeight z_tol rot_tol imuAvailable imuRoll imuPitch]\n", argv[0]);
+            return 2;
+        }
         liorf_amd::MapOptimizationS2M node;                 // throws without a gfx950 device
         node.laserCloudSurfFromMapDS = read_cloud(argv[1]);
         node.laserCloudSurfLastDS = read_cloud(argv[2]);
         node.haveKeyPoses = !node.laserCloudSurfFromMapDS.empty();
         for (int k = 0; k < 6; k++) node.transformTobeMapped[k] = (float)std::atof(argv[3 + k]);
+        if (argc == 16) {       // members set after construction, like ParamServer's yaml values
+            node.imuType = std::atoi(argv[9]);
+            node.imuRPYWeight = (float)std::atof(argv[10]);
+            node.z_tollerance = (float)std::atof(argv[11]);
+            node.rotation_tollerance = (float)std::atof(argv[12]);
+            node.cloudInfo.imuAvailable = std::atoll(argv[13]);
+            node.cloudInfo.imuRollInit = (float)std::atof(argv[14]);
+            node.cloudInfo.imuPitchInit = (float)std::atof(argv[15]);
+        }
         node.setInputCloud();
         node.scan2MapOptimization();
         print_result(node);

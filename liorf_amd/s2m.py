@@ -25,7 +25,7 @@ ERRORS = {-1: "S2M_ERR_INVALID_ARG", -2: "S2M_ERR_NO_DEVICE", -3: "S2M_ERR_HIP",
 
 # every symbol include/liorf_s2m.h declares
 ABI_SYMBOLS = [
-    "s2m_version", "s2m_default_params", "s2m_create", "s2m_destroy", "s2m_last_error",
+    "s2m_version", "s2m_default_params", "s2m_create", "s2m_destroy", "s2m_last_error", "s2m_set_params", "s2m_get_params",
     "s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device",
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
@@ -121,6 +121,8 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_default_params.argtypes = [C.POINTER(Params)]
     L.s2m_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     L.s2m_destroy.argtypes = [vp]
+    L.s2m_set_params.argtypes = [vp, C.POINTER(Params)]
+    L.s2m_get_params.argtypes = [vp, C.POINTER(Params)]
     for n in ("s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device"):
         getattr(L, n).argtypes = [vp, vp, C.c_size_t, C.c_size_t]
     L.s2m_optimize.argtypes = [vp, vp, C.c_size_t, C.c_size_t, fp, C.POINTER(ImuInit), C.POINTER(Result)]
@@ -209,6 +211,13 @@ class MapOptimizationS2M:
         if rc != S2M_OK:
             msg = self.lib.s2m_last_error(self.h)
             raise S2MError(f"{what}: {ERRORS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    def setParams(self, **kw):
+        """s2m_set_params: the ParamServer values the path reads at every call in the reference
+        (z_tol, rot_tol, imu_type, imu_rpy_weight) and the loop constants, changed after construction."""
+        for k, v in kw.items():
+            setattr(self.params, k, v)
+        self._check(self.lib.s2m_set_params(self.h, C.byref(self.params)), "s2m_set_params")
 
     # -- inputs ------------------------------------------------------------
     def setInputCloud(self, laserCloudSurfFromMapDS):

@@ -208,6 +208,13 @@ class Oracle:
         lib().orc_scan2MapOptimization(self.h, C.byref(imu) if imu is not None else None, C.byref(r))
         return r
 
+    def transformUpdate(self, pose, imu: ImuInit | None = None):
+        """transformUpdate() (reference :1323-1353) applied to `pose`: (transformTobeMapped, incrementalOdometryAffineBack 3x4)."""
+        self.set_pose(pose)
+        lib().orc_transformUpdate(self.h, C.byref(imu) if imu is not None else None)
+        p = self.get_pose()
+        return p, getTransformation(p)
+
     def trace(self):
         buf = (IterTrace * 64)()
         n = lib().orc_get_trace(self.h, buf, 64)

@@ -789,8 +789,8 @@ static float constraintTransformation(float value, float limit)      /* :1355-13
 void orc_transformUpdate(orc_ctx* c, const orc_imu_init* imu)
 {
     float* t = c->transformTobeMapped;
-    if (imu && imu->imuAvailable && c->p.imu_type) {                 /* :1325 */
-        if (fabsf(imu->imuPitchInit) < 1.4f) {                       /* std::abs(float) < 1.4 :1327 */
+    if (imu && imu->imuAvailable == 1 && c->p.imu_type) {            /* `cloudInfo.imuAvailable == true` :1325: the int64 field against 1 */
+        if ((double)fabsf(imu->imuPitchInit) < 1.4) {                /* std::abs(float) < 1.4 :1327: float promoted, double compare */
             double w = (double)c->p.imu_rpy_weight, r, p, y;
             quat_get_rpy(quat_slerp(quat_rpy(t[0], 0, 0), quat_rpy(imu->imuRollInit, 0, 0), w), &r, &p, &y);
             t[0] = (float)r;                                         /* :1338 */
