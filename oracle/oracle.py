@@ -302,6 +302,14 @@ def _dp(a):
     return a.ctypes.data_as(C.POINTER(C.c_double))
 
 
+def make_ringkey(desc) -> np.ndarray:
+    """makeRingkeyFromScancontext (reference include/Scancontext.cpp:198-211): 20 row means (fp64)."""
+    d = np.ascontiguousarray(desc, np.float64).reshape(20, 60)
+    key = np.zeros(20, np.float64)
+    lib().orc_makeRingkeyFromScancontext(_dp(d), _dp(key))
+    return key
+
+
 def distance_btn_scancontext(sc1, sc2):
     """distanceBtnScanContext (reference include/Scancontext.cpp:116-148): (dist, shift)."""
     a = np.ascontiguousarray(sc1, np.float64).reshape(20, 60)
@@ -418,3 +426,23 @@ def nanoflann_knn5(map_xyz, q_xyz, leaf_max: int = 15):
     rc = _NF.nfref_knn5(_fp(m), m.shape[0], _fp(q), q.shape[0], _ip(idx), _fp(d2), leaf_max)
     assert rc == 0
     return idx, d2
+
+
+def nanoflann_ringkey_knn(keys, query, k: int = 3):
+    """SCManager's ring-key search run through the reference's own KDTreeVectorOfVectorsAdaptor + nanoflann
+    (oracle/_ref, built by oracle/Makefile from /root/reference/include): (indices[k], squared distances[k], found).
+    None when the cross-check library is absent."""
+    global _NF
+    if nanoflann_knn5(np.zeros((5, 3), np.float32), np.zeros((1, 3), np.float32)) is None:
+        return None
+    if not hasattr(_NF, "_ringkey_ready"):
+        _NF.nfref_ringkey_knn.argtypes = [C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_float), C.c_int,
+                                          C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+        _NF._ringkey_ready = True
+    a = np.ascontiguousarray(keys, np.float32)
+    q = np.ascontiguousarray(query, np.float32)
+    idx = np.zeros(k, np.int64)
+    d2 = np.zeros(k, np.float32)
+    found = _NF.nfref_ringkey_knn(_fp(a), a.shape[0], a.shape[1], _fp(q), k, idx.ctypes.data_as(C.POINTER(C.c_int64)), _fp(d2))
+    assert found >= 0
+    return idx, d2, found

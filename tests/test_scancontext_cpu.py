@@ -24,6 +24,18 @@ def revisit(d, shift, noise, seed):
     return np.where(np.roll(d, shift, axis=1) == 0, 0.0, r)
 
 
+def sequence_340():
+    """The 340-key-frame sequence of the loop-detector tests: random descriptors, from frame 60 on every 13th frame
+    revisits the place of 50 frames earlier, rotated and with noise (crosses the device store's first growth at 256)."""
+    descs = make_descriptors(340, seed=3)
+    out = []
+    for i, d in enumerate(descs):
+        if i >= 60 and i % 13 == 0:
+            d = revisit(descs[i - 50], shift=(11 * i) % 60, noise=0.05, seed=i)
+        out.append(d)
+    return out
+
+
 def numpy_dist_direct(sc1, sc2):
     n1, n2 = np.linalg.norm(sc1, axis=0), np.linalg.norm(sc2, axis=0)
     ok = (n1 != 0) & (n2 != 0)
@@ -88,3 +100,57 @@ def test_detect_loop_sequence():
     d2 = ((keys[:n_search] - keys[99]) ** 2).sum(1)
     assert sorted(det["cand_idx"]) == sorted(np.argsort(d2, kind="stable")[:3].tolist())
     m.close()
+
+
+# ----------------------------------------------------------------------------- the reference's own ring-key search
+import os
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sc_ringkey_ref_golden.npz")
+
+
+def test_ringkey_candidates_equal_the_references_adaptor():
+    """Step 1 of detectLoopClosureID (reference :288-296) PINNED: the oracle's 3 ring-key candidates and squared
+    distances against the reference's own KDTreeVectorOfVectorsAdaptor + nanoflann (compiled from /root/reference
+    into oracle/_ref), live when that library is present, and against the fixture it wrote
+    (tests/golden/sc_ringkey_ref_golden.npz, made by tests/golden/make_golden_ringkey.py) always."""
+    g = np.load(GOLD)
+    descs = sequence_340()
+    keys = np.stack([O.make_ringkey(d).astype(np.float32) for d in descs])
+    assert np.array_equal(keys.view(np.uint32), g["ringkeys"].view(np.uint32)), "the test sequence changed: regenerate the fixture"
+    live = O.nanoflann_ringkey_knn(keys[:5], keys[5], 3) is not None
+    orc = O.SCManager()
+    checked = 0
+    for i, d in enumerate(descs):
+        orc.add_descriptor(d)
+        lid, yaw, om = orc.detectLoopClosureID()
+        if i < 30:
+            continue
+        ns = int(g["n_search"][i])
+        assert ns >= 1
+        assert om["cand_idx"] == g["cand_idx"][i].tolist(), i
+        assert np.array_equal(np.array(om["cand_d2"], np.float32).view(np.uint32), g["cand_d2"][i].view(np.uint32)), i
+        if live:
+            idx, d2, found = O.nanoflann_ringkey_knn(keys[:ns], keys[i], 3)
+            assert idx[:found].tolist() == om["cand_idx"][:found] and np.array_equal(d2[:found], np.array(om["cand_d2"], np.float32)[:found])
+        checked += 1
+    assert checked == 310
+    orc.close()
+
+
+def test_ringkey_search_with_fewer_keys_than_candidates_and_ties():
+    """1 and 2 keys in the tree (the result vectors keep their zero initialisation, :289-290), and duplicated keys
+    (a robot standing still): where distances tie exactly, nanoflann returns them in tree-traversal order - the
+    oracle breaks ties towards the lower index, so only the distances and the SET of tied indices are comparable."""
+    if O.nanoflann_ringkey_knn(np.zeros((2, 20), np.float32), np.zeros(20, np.float32), 3) is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    rng = np.random.default_rng(4)
+    keys = rng.uniform(0, 3, (40, 20)).astype(np.float32)
+    q = rng.uniform(0, 3, 20).astype(np.float32)
+    for ns in (1, 2):
+        idx, d2, found = O.nanoflann_ringkey_knn(keys[:ns], q, 3)
+        assert found == ns
+    keys[7] = keys[3]
+    keys[21] = keys[3]
+    idx, d2, found = O.nanoflann_ringkey_knn(keys, keys[3] + np.float32(0.01), 3)
+    assert sorted(idx.tolist()) == [3, 7, 21] and d2[0] == d2[1] == d2[2]

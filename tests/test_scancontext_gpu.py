@@ -7,7 +7,7 @@ import pytest
 
 from liorf_amd import s2m, synth
 from oracle import oracle as O
-from test_scancontext_cpu import make_descriptors, revisit
+from test_scancontext_cpu import GOLD, make_descriptors, revisit, sequence_340
 
 pytestmark = pytest.mark.gpu
 
@@ -19,14 +19,30 @@ def gpu():
     g.close()
 
 
+def test_ringkey_candidates_equal_the_reference(gpu):
+    """k_sc_detect's ring-key 3-NN against data derived from the reference itself: the candidates and squared
+    distances its own KDTreeVectorOfVectorsAdaptor + nanoflann return for this sequence (fixture written by
+    tests/golden/make_golden_ringkey.py from /root/reference/include; no oracle in this comparison)."""
+    g = np.load(GOLD)
+    descs = sequence_340()
+    gpu.scReset()
+    for i, d in enumerate(descs):
+        gpu.scAddDescriptor(d)
+        lid, yaw, m = gpu.detectLoopClosureID()
+        if i < 30:
+            assert lid == -1
+            continue
+        assert list(m.cand_idx) == g["cand_idx"][i].tolist(), i
+        assert np.array_equal(np.array(m.cand_d2, np.float32).view(np.uint32), g["cand_d2"][i].view(np.uint32)), i
+    assert gpu.scSize() == 340
+
+
 def test_detect_loop_sequence_matches_oracle(gpu):
-    descs = make_descriptors(340, seed=3)           # crosses the store's first growth (256)
+    descs = sequence_340()                          # crosses the store's first growth (256)
     gpu.scReset()
     orc = O.SCManager()
     loops = 0
     for i, d in enumerate(descs):
-        if i >= 60 and i % 13 == 0:
-            d = revisit(descs[i - 50], shift=(11 * i) % 60, noise=0.05, seed=i)
         gpu.scAddDescriptor(d)
         orc.add_descriptor(d)
         lid, yaw, m = gpu.detectLoopClosureID()
