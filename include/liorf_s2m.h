@@ -183,6 +183,11 @@ int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, floa
  * and cost more than the steady state. */
 int  s2m_time_iterations(s2m_handle h, const float pose[6], int reps, float* ms_per_iter, int cap);
 
+/* Diagnostics: a full loop from `pose` (early_exit must be off), then `reps` back-to-back replays of its last registration
+ * launch in the state the loop ended in; solve_prev != 0 closes the iteration before it in the launch's prologue each time
+ * (the steady launch of the fused loop), 0 only rebuilds the transform.  Mean microseconds per replayed launch, gaps included. */
+int  s2m_debug_time_steady(s2m_handle h, const float pose[6], int reps, int solve_prev, float* us_per_launch);
+
 /* Diagnostics: `launches` > 0: that many k_register passes at `pose`, the last one recorded (1 = the pass
  * that inherits its prior from whatever ran before, 3 = steady state at this pose). `launches` < 0: a real LM
  * loop from `pose` exactly as s2m_optimize issues it, of which launch number N = -launches - 1 is recorded

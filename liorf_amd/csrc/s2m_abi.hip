@@ -47,7 +47,7 @@ struct s2m_context {
     // map side
     DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
     // scan side
-    DevBuf raw_scan, qx, qy, qz, qperm, prevp, prior_valid, plane_cache, plane_state, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
+    DevBuf raw_scan, qx, qy, qz, qperm, npos, cert, aux, plane_cache, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
     // voxel-grid stages that feed the path (section 8(f) F1/F2): staging for host clouds, transformed key frames, filtered clouds
@@ -191,7 +191,10 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
     // cell edge: every map point with fp32 d2 < gate_sq of a query lies in the 3x3x3 block
     // around the query's cell once E >= sqrt(gate_sq) plus a margin that covers the fp32
     // rounding of (v - o) * inv_e (<= 2.4e-5 cells at |v - o| <= 200).
-    double E = std::sqrt(h->prm.gate_sq) * (1.0 + 1.0 / 1024.0);
+    // The edge is 2.5 % above the gate: a query's 3x3x3 cells then cover a ball of that much more than the gate around it,
+    // which is what lets a point with fewer than 5 neighbours inside the gate prove "and none just outside it either" and
+    // keep that verdict over the following launches (s2m_register.hpp, tier A) instead of searching again.
+    double E = std::sqrt(h->prm.gate_sq) * 1.025;
     GridDesc g{};
     for (int attempt = 0; attempt < 32; attempt++) {
         const float Ef = (float)E;
@@ -226,8 +229,10 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
                        (const int32_t*)h->m_cell_start.as<int32_t>(), h->map_sorted.as<float4>());
     S2M_HIP(h, hipGetLastError());
 
-    if (h->have_scan && h->n_q > 0 && h->prior_valid.p)      // neighbours of the old map are meaningless now
-        S2M_HIP(h, hipMemsetAsync(h->prior_valid.p, 0, sizeof(int32_t) * h->n_q, h->stream));
+    if (h->have_scan && h->n_q > 0 && h->cert.p) {           // tuples and certificates of the old map are meaningless now
+        S2M_HIP(h, hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream));
+        S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int2) * h->n_q, h->stream));
+    }
     h->n_m = n;                                       // committed only now: a failure above leaves the old index in place
     h->hctx.n_m = (int32_t)n;
     h->hctx.g = g;
@@ -259,7 +264,10 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     int nblocks = (n_chunks * base_parts + n_chunks / 2 + NW - 1) / NW;
     nblocks = ((nblocks + kBlocksQuantum - 1) / kBlocksQuantum) * kBlocksQuantum;
     if (nblocks == 0) nblocks = kBlocksQuantum;
+    const int table_cap = nblocks * NW;                   // wave-table entries: every chunk plus the budget for split chunks
+    nblocks = std::min(nblocks, kMaxBlocks);               // the grid stays co-resident: waves loop over the table
     h->hctx.nblocks = nblocks;
+    h->hctx.table_cap = table_cap;
     h->ctx_dirty = true;
     if ((rc = ensure(h, h->partials, sizeof(double) * 2 * kAcc * (size_t)nblocks))) return rc;   // two slots, by launch parity
     h->hctx.partials = h->partials.as<double>();
@@ -278,10 +286,10 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     if ((rc = ensure(h, h->qy, sizeof(float) * n))) return rc;
     if ((rc = ensure(h, h->qz, sizeof(float) * n))) return rc;
     if ((rc = ensure(h, h->qperm, sizeof(int32_t) * n))) return rc;
-    if ((rc = ensure(h, h->prevp, sizeof(float4) * 5 * n))) return rc;
+    if ((rc = ensure(h, h->npos, sizeof(int32_t) * 5 * n))) return rc;
     if ((rc = ensure(h, h->plane_cache, sizeof(float4) * n))) return rc;
-    if ((rc = ensure(h, h->plane_state, sizeof(int32_t) * n))) return rc;
-    if ((rc = ensure(h, h->prior_valid, sizeof(int32_t) * n))) return rc;     // both are reset by k_scatter_scan
+    if ((rc = ensure(h, h->cert, sizeof(float4) * n))) return rc;           // cert and aux are reset by k_scatter_scan
+    if ((rc = ensure(h, h->aux, sizeof(int2) * n))) return rc;
     if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
     if ((rc = ensure(h, h->q_rank_of, sizeof(int32_t) * n))) return rc;
@@ -296,13 +304,13 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
                        (const int32_t*)h->q_cell_of.as<int32_t>(), (const int32_t*)h->q_rank_of.as<int32_t>(),
                        (const int32_t*)h->q_cell_start.as<int32_t>(),
                        h->qx.as<float>(), h->qy.as<float>(), h->qz.as<float>(), h->qperm.as<int32_t>(),
-                       h->prior_valid.as<int32_t>(), h->plane_state.as<int32_t>());
+                       h->cert.as<float4>(), h->aux.as<int2>());
     S2M_HIP(h, hipGetLastError());
 
     h->hctx.qx = h->qx.as<float>(); h->hctx.qy = h->qy.as<float>(); h->hctx.qz = h->qz.as<float>();
     h->hctx.qperm = h->qperm.as<int32_t>();
     {
-        const int capacity = h->hctx.nblocks * (kBlock / 64);
+        const int capacity = table_cap;
         if ((rc = ensure(h, h->chunk_parts, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
         {   // density wishes: all zero between uses (k_chunk_table_density clears what it consumes)
             const void* before = h->chunk_factor.p;
@@ -325,10 +333,10 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
         h->hctx.n_chunks = n_chunks;
         h->hctx.density_pending = 1;
     }
-    h->hctx.prevp = h->prevp.as<float4>();
-    h->hctx.prior_valid = h->prior_valid.as<int32_t>();
+    h->hctx.npos = h->npos.as<int32_t>();
+    h->hctx.cert = h->cert.as<float4>();
+    h->hctx.aux = h->aux.as<int2>();
     h->hctx.plane_cache = h->plane_cache.as<float4>();
-    h->hctx.plane_state = h->plane_state.as<int32_t>();
     h->ctx_dirty = true;
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
     h->scan_timing_pending = true;
@@ -379,7 +387,7 @@ void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* eve
     if (h->density_raw > 0) {
         // re-split the wave table for the map density at the initial guess (the transform k_set_state just stored);
         // both kernels take everything from the DevCtx block, so the captured graph stays valid from scan to scan
-        hipLaunchKernelGGL(k_wave_density, dim3((nblocks * (kBlock / 64) + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
+        hipLaunchKernelGGL(k_wave_density, dim3((h->hctx.table_cap + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
                            h->density_raw);
         hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, const_cast<DevCtx*>(dc), st);
     }
@@ -393,7 +401,8 @@ void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* eve
 
 int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
 {
-    auto it = h->graphs.find(nblocks);
+    const int key = h->hctx.table_cap;                    // fixes both grids in the captured loop: k_register's (nblocks) and k_wave_density's
+    auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { *out = it->second; return S2M_OK; }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
@@ -405,7 +414,7 @@ int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "hipGraphInstantiate", e);
-    h->graphs[nblocks] = exec;
+    h->graphs[key] = exec;
     *out = exec;
     return S2M_OK;
 }
@@ -438,6 +447,7 @@ int launch_loop(s2m_context* h)
 void params_to_ctx(s2m_context* h, const s2m_params& prm)
 {
     h->hctx.gate_f = nextafterf((float)prm.gate_sq, INFINITY);
+    h->hctx.gate_r = nextafterf(sqrtf((float)prm.gate_sq), 0.0f);
     h->hctx.gate_sq = prm.gate_sq; h->hctx.plane_tol = prm.plane_tol; h->hctx.weight_scale = prm.weight_scale;
     h->hctx.weight_min = prm.weight_min; h->hctx.conv_deg = prm.conv_deg; h->hctx.conv_cm = prm.conv_cm;
     h->hctx.eig_thresh = prm.eig_thresh; h->hctx.min_corr = prm.min_corr; h->hctx.max_iter = prm.max_iter;
@@ -623,7 +633,7 @@ int s2m_destroy(s2m_handle h)
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
-                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->prevp, &h->prior_valid, &h->plane_cache, &h->plane_state, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->npos, &h->cert, &h->aux, &h->plane_cache, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out,
                        &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds,
@@ -809,7 +819,7 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
     if (!h || !pose || !out || launches == 0) return S2M_ERR_INVALID_ARG;
     if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
     S2M_HIP(h, hipSetDevice(h->device));
-    const size_t nwaves = (size_t)h->hctx.nblocks * (kBlock / 64);   // kWaveQ points each
+    const size_t nwaves = (size_t)h->hctx.nblocks * (kBlock / 64);   // one record per wave of the grid
     int rc;
     if ((rc = ensure(h, h->dbg_clk, sizeof(uint64_t) * kProfWords * nwaves))) return rc;
     S2M_HIP(h, hipMemsetAsync(h->dbg_clk.p, 0, sizeof(uint64_t) * kProfWords * nwaves, h->stream));
@@ -824,7 +834,7 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
         const int nblocks = h->hctx.nblocks, N = -launches - 1;
         const bool fuse = h->fuse_solve && nblocks <= h->fuse_max_blocks;
         if (h->density_raw > 0) {
-            hipLaunchKernelGGL(k_wave_density, dim3((nblocks * (kBlock / 64) + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
+            hipLaunchKernelGGL(k_wave_density, dim3((h->hctx.table_cap + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
                                h->density_raw);
             hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, const_cast<DevCtx*>(dc), st);
         }
@@ -924,8 +934,8 @@ static int time_iterations_impl(s2m_handle h, const float pose[6], int reps, flo
     std::vector<double> per_iter((size_t)nit, 0.0);
     for (int rep = 0; rep < reps; rep++) {
         // a new scan starts without a prior or cached planes (what s2m_set_scan leaves behind)
-        S2M_HIP(h, hipMemsetAsync(h->prior_valid.p, 0, sizeof(int32_t) * h->n_q, h->stream));
-        S2M_HIP(h, hipMemsetAsync(h->plane_state.p, 0, sizeof(int32_t) * h->n_q, h->stream));
+        S2M_HIP(h, hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream));
+        S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int2) * h->n_q, h->stream));
         if ((rc = push_state(h, pose))) return rc;
         enqueue_loop(h, h->hctx.nblocks, dc, h->iter_events.data());     // the real loop, launched one by one between event pairs
         h->hctx.density_pending = 0;
@@ -943,6 +953,34 @@ static int time_iterations_impl(s2m_handle h, const float pose[6], int reps, flo
         if (ms_per_iter) ms_per_iter[it] = (float)(per_iter[(size_t)it] / reps);
     }
     if (ms_mean) *ms_mean = (float)(total / ((double)reps * nit));
+    return S2M_OK;
+}
+
+// Diagnostics: one full loop from `pose` (max_iter iterations, so early_exit should be off), then `reps` back-to-back
+// replays of the loop's last registration launch in the state the loop ended in (nearly every point certified):
+// solve_prev = 1 closes the iteration before it in its prologue each time (the steady launch of the fused loop),
+// 0 rebuilds the transform only.  Returns the mean time per replayed launch, gaps included.
+int s2m_debug_time_steady(s2m_handle h, const float pose[6], int reps, int solve_prev, float* us_per_launch)
+{
+    if (!h || !pose || reps < 1 || !us_per_launch) return S2M_ERR_INVALID_ARG;
+    if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
+    float p[6];
+    memcpy(p, pose, 24);
+    s2m_result r;
+    int rc = s2m_optimize_resident(h, p, nullptr, &r);
+    if (rc) return rc;
+    if (r.skipped || r.iters_run != h->prm.max_iter) return fail(h, S2M_ERR_INVALID_ARG, "the loop ended early: switch early_exit off");
+    const DevCtx* dc = h->dctx.as<DevCtx>();
+    const int L = h->prm.max_iter;
+    S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
+    for (int k = 0; k < reps; k++)
+        hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, h->state.as<DevState>(), L, solve_prev ? 1 : 0);
+    S2M_HIP(h, hipGetLastError());
+    S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    S2M_HIP(h, hipEventElapsedTime(&ms, h->ev_c, h->ev_d));
+    *us_per_launch = ms * 1e3f / (float)reps;
     return S2M_OK;
 }
 

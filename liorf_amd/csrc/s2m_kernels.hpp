@@ -107,6 +107,30 @@ S2M_HD inline float glibc_sincosf(float y, int which)
     return which ? (float)cos(x) : (float)sin(x);
 }
 
+// Both at once for the launches that rebuild the transform: one argument reduction, and the two polynomials (independent
+// chains) side by side; glibc's sinf and cosf share the reduction and differ only in which polynomial they return.
+S2M_HD inline void glibc_sincosf_both(float y, float& sn, float& cs)
+{
+    double x = (double)y;
+    int n = 0;
+    int tbl = 0;
+    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {                      // |y| < pi/4
+        if (abstop12(y) < abstop12(0x1p-12f)) { sn = y; cs = 1.0f; return; }
+    } else if (abstop12(y) < abstop12(120.0f)) {
+        const SincosfTable& p0 = sincosf_table(0);
+        const double r = x * p0.hpi_inv;
+        n = ((int32_t)r + 0x800000) >> 24;
+        x = x - (double)n * p0.hpi;
+        x = x * p0.sign[n & 3];
+        tbl = (n & 2) ? 1 : 0;
+    } else { sn = (float)sin(x); cs = (float)cos(x); return; }
+    const SincosfTable& p = sincosf_table(tbl);
+    const double x2 = x * x;
+    const float a = sinf_poly(x, x2, p, 0), b = sinf_poly(x, x2, p, 1);
+    sn = (n & 1) ? b : a;
+    cs = (n & 1) ? a : b;
+}
+
 // atanf as glibc computes it (sysdeps/ieee754/flt-32/s_atanf.c: the fdlibm algorithm in fp32 [ext]; no FMA
 // variant exists for it): SCManager's xy2theta (include/Scancontext.cpp:23-36) calls atan on a float, i.e. the
 // host's atanf, and a sector index is the ceiling of the angle - one ulp decides on which side of a sector
@@ -393,8 +417,7 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
                                const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
                                const int32_t* __restrict__ cell_start,
                                float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz,
-                               int32_t* __restrict__ qperm, int32_t* __restrict__ prior_valid,
-                               int32_t* __restrict__ plane_state)
+                               int32_t* __restrict__ qperm, float4* __restrict__ cert, int2* __restrict__ aux)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -402,7 +425,8 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
     int pos = cell_start[cell_of[i]] + rank_of[i];
     if ((unsigned)pos >= (unsigned)n) return;            // cannot happen while the histogram is consistent
     qx[pos] = p[0]; qy[pos] = p[1]; qz[pos] = p[2]; qperm[pos] = i;
-    prior_valid[pos] = 0; plane_state[pos] = 0;          // a new scan has no prior and no cached planes
+    cert[pos] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // a new scan: no certificate (slack 0), no neighbour tuple, no plane
+    aux[pos] = make_int2(0, 0);
 }
 
 // Work-proportional wave assignment.  The sorted scan is cut into chunks of 64 points; a chunk
@@ -567,7 +591,7 @@ __global__ __launch_bounds__(1024) void k_chunk_table_density(DevCtx* __restrict
     if (!cp->density_pending) return;                     // once per scan (the flag is uniform: read before the barrier below)
     __syncthreads();
     if (threadIdx.x == 0) cp->density_pending = 0;
-    chunk_table_body(cp->chunk_parts, cp->n_q, cp->n_chunks, cp->nblocks * (kBlock / 64), cp->wave_table_rw, cp->n_waves_rw,
+    chunk_table_body(cp->chunk_parts, cp->n_q, cp->n_chunks, cp->table_cap, cp->wave_table_rw, cp->n_waves_rw,
                      cp->chunk_factor, st);
 }
 
@@ -715,50 +739,7 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 }
 
 // ------------------------------------------------------------------------------------------
-// k_register: one launch = one surfOptimization() pass (:1074-1143) fused with the matA/matB
-// row assembly of LMOptimization() (:1191-1235) and the first stage of the AtA / AtB
-// reduction (:1237-1239); in the fused loop its prologue also closes the previous LM iteration
-// (lm_close_iteration below).  One lane = one scan point, one wave = up to 64 locality-sorted
-// points (8, 16 or 32 for chunks that k_chunk_parts / k_wave_density cut finer), 8 waves per
-// workgroup, <= 2 workgroups per CU.
-//
-// The L2 of this multi-die part starts cold at every kernel boundary (40 % TCC misses per launch,
-// profiles/), so a dependent global round trip costs 0.5-1 us and the kernel is organised around
-// having few of them per wave:
-//
-//   round trip 0  the loop state block (kernel argument): `done`, the wave count, the pose
-//   round trip 1  scan point + PRIOR (the 5 neighbours this point had in the previous launch,
-//                 kept as coordinates + index; any 5 distinct map points would do) + cached plane.
-//                 Re-measured at the new pose, the prior's 5th distance - capped at the gate,
-//                 beyond which nothing is observable - is an exact upper bound on this launch's
-//                 5th-neighbour distance: map rows and cells whose slab is farther away are never
-//                 touched.  The LM loop revisits the same scan up to 30 times with an ever smaller
-//                 pose step, so from the second launch on the bound is tight.
-//   (DPP)         wave bounding box of the transformed points -> box of grid cells (+1 halo)
-//   TILE path (compact waves, the common case)
-//   round trip 2  bounds of the box rows that some lane still needs
-//   round trip 3  the non-empty ones among those rows (contiguous runs of the cell-sorted map, 8 rows
-//                 in flight, 16 lanes a row) are filtered against the waves's point box grown by the
-//                 largest bound and compacted into the wave's LDS tile.
-//                 verify: every lane counts the tile points inside its bound (branch-free; lanes of
-//                 a short wave share the work).  Exactly 5 with a complete prior: the ordered
-//                 neighbour set is the prior.  Fewer than 5 inside the gate: not gated.
-//                 otherwise: the lane lists the tile positions inside its radius (no prior: the
-//                 tightest of four radii that still holds 5 points) and the wave inserts the lanes'
-//                 k-th candidates together - a handful of insertion steps instead of one per tile
-//                 point.  A superset of a lane's neighbourhood cannot change its gated result.
-//   GATHER path (scattered waves: more than kRowMax box rows, a tile that would overflow)
-//   round trip 2  bounds of the <= 9 x-runs of each lane's own 3x3x3 neighbourhood
-//   round trip 3+ the runs, one after the other, the next one prefetched: count first, full
-//                 insertion pass only for lanes whose count is not 5
-//   -> exact top-5 by (d2, map index), coordinates carried along -> gate -> LS plane (re-used
-//   bit for bit when the ordered neighbour tuple is unchanged) -> inlier test -> weight ->
-//   Jacobian row -> 21+6+1 fp64 products per lane -> recursive-halving wave reduction + LDS
-//   across the 8 waves -> one partial row per workgroup, in the slot of this launch's parity.
-//
-// No barrier is needed until the final reduction (and the two inside the fused close): a wave only
-// reads LDS it wrote itself.  combineOptimizationCoeffs() (:1145-1156) has no counterpart:
-// rejected lanes contribute zeros.
+// shared constants and wave-level helpers of the registration kernel (s2m_register.hpp)
 // ------------------------------------------------------------------------------------------
 constexpr int kTilePts = 320;        // points per wave tile (5 KiB) after filtering
 constexpr int kTileRaw = 448;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
@@ -766,45 +747,6 @@ constexpr int kCand = 24;            // candidate-list capacity per lane (tile p
 constexpr int kRowMax = 256;         // boxes with more rows go straight to the gather path
 constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning (<= 5e-5)
 constexpr uint64_t kKeyInf = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu;
-
-// exact top-5: key = (fp32 d2 bits << 32) | original map index, ascending; coordinates ride along
-struct Top5 { uint64_t key[5]; float x[5], y[5], z[5]; };
-
-__device__ __forceinline__ void top5_insert(Top5& t, uint64_t key, float x, float y, float z)
-{
-    t.key[4] = key; t.x[4] = x; t.y[4] = y; t.z[4] = z;
-#pragma unroll
-    for (int j = 4; j > 0; --j) {
-        const uint64_t ka = t.key[j - 1], kb = t.key[j];
-        const bool c = kb < ka;
-        t.key[j - 1] = c ? kb : ka; t.key[j] = c ? ka : kb;
-        swap_if(c, t.x[j - 1], t.x[j]); swap_if(c, t.y[j - 1], t.y[j]); swap_if(c, t.z[j - 1], t.z[j]);
-    }
-}
-
-__device__ __forceinline__ uint64_t make_key(const v4f m, float sx, float sy, float sz, float& d2)
-{
-    const float dx = sx - m.x, dy = sy - m.y, dz = sz - m.z;
-    d2 = (dx * dx + dy * dy) + dz * dz;                                               // L2_Simple order
-    return ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(m.w);
-}
-
-// bound = min(d2 of the current 5th best, gate): nothing at or beyond the gate is observable
-__device__ __forceinline__ void consider(Top5& best, float& bound, float gatef, const v4f m, float sx, float sy, float sz)
-{
-    float d2;
-    const uint64_t key = make_key(m, sx, sy, sz, d2);
-    const uint32_t idx = (uint32_t)key;
-    // one straight-line predicate, one branch. A map point already in the set (the prior's points
-    // are met again; the gather path re-reads the last point of a run) has the same index.
-    const bool pass = (d2 <= bound) & (key < best.key[4]) &
-                      (idx != (uint32_t)best.key[0]) & (idx != (uint32_t)best.key[1]) &
-                      (idx != (uint32_t)best.key[2]) & (idx != (uint32_t)best.key[3]);
-    if (pass) {
-        top5_insert(best, key, m.x, m.y, m.z);
-        bound = fminf(__uint_as_float((uint32_t)(best.key[4] >> 32)), gatef);
-    }
-}
 
 // LDS written by this wave is read back by other lanes of the same wave: DS operations of one
 // wave execute in order, so only the compiler has to be kept from reordering them.
@@ -851,6 +793,16 @@ __device__ __forceinline__ int wave_max_i32(int v)
     v = max(v, dpp_i32<0x114, 0xf>(ID, v)); v = max(v, dpp_i32<0x118, 0xf>(ID, v));
     v = max(v, dpp_i32<0x142, 0xa>(ID, v)); v = max(v, dpp_i32<0x143, 0xc>(ID, v));
     return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t u)
+{
+    constexpr int ID = -1;                                   // 0xffffffff
+    int v = (int)u;
+    auto mn = [](int a, int b) { return (int)min((uint32_t)a, (uint32_t)b); };
+    v = mn(v, dpp_i32<0x111, 0xf>(ID, v)); v = mn(v, dpp_i32<0x112, 0xf>(ID, v));
+    v = mn(v, dpp_i32<0x114, 0xf>(ID, v)); v = mn(v, dpp_i32<0x118, 0xf>(ID, v));
+    v = mn(v, dpp_i32<0x142, 0xa>(ID, v)); v = mn(v, dpp_i32<0x143, 0xc>(ID, v));
+    return (uint32_t)__builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ uint32_t wave_or_u32(uint32_t u)
 {
@@ -996,12 +948,17 @@ __device__ __forceinline__ float lane_bcast(float v, int src_lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src_lane));
 }
 
-// element `idx` (0..5, per lane) of a register array: a select chain, no scratch
+// element `idx` (0..5, per lane) of a register array as a select chain.  Left alone, the compiler recognises the chain
+// as a dynamically indexed array and goes through scratch memory (a store and a dependent load: ~0.2 us each, twelve of
+// them in the solve); the empty asm statements keep the selects apart.
 __device__ __forceinline__ float pick6(const float (&a)[6], int idx)
 {
     float r = a[0];
 #pragma unroll
-    for (int i = 1; i < 6; i++) r = (idx == i) ? a[i] : r;
+    for (int i = 1; i < 6; i++) {
+        r = (idx == i) ? a[i] : r;
+        asm volatile("" : "+v"(r));
+    }
     return r;
 }
 
@@ -1329,645 +1286,7 @@ __global__ __launch_bounds__(256) void k_wave_density(const DevCtx* __restrict__
     if (lane == 0 && f > 1) atomicMax(&cp->chunk_factor[e.x >> 6], f);
 }
 
-template <bool HOOK>
-__global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int launch, int solve_prev)
-{
-    constexpr int NW = kBlock / 64;
-    // The loop state block never moves, so it comes as a kernel argument: `done` and the wave count arrive
-    // with the first round trip, in parallel with the DevCtx block, instead of behind a pointer chase.
-    const auto st = G(state);
-    const int done = st->done, n_waves = st->n_waves;
-    if (!HOOK && done) return;
-    unsigned long long tk_start = 0, tk = 0, t_bbox = 0, t_mark = 0, t_stage = 0, t_search = 0;
-    unsigned long long lm_stamps[7] = { 0, 0, 0, 0, 0, 0, 0 };   // diagnostics of the fused LM close
-    if (HOOK) { tk_start = wall_clock64(); tk = tk_start; }
-#define S2M_LAP(acc) do { if (HOOK) { const unsigned long long n__ = wall_clock64(); (acc) += n__ - tk; tk = n__; } } while (0)
-
-    __shared__ v4f     s_pts[NW][kTilePts];          // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
-    static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
-    __shared__ double  red[NW][32];
-    __shared__ uint16_t s_cand[NW][kCand * 64];     // per wave: tile positions of each lane's candidates, [k][lane]
-    __shared__ int2    s_rows[NW][64];              // per wave: the non-empty box rows of the current row group
-    __shared__ float   s_lm_out[8];                  // pose + loop-ended flag published by lm_close_iteration
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // wave w of workgroup b takes entry w*gridDim.x + b of the wave table: neighbouring chunks
-    // (similar cost: the sort runs from the dense near field to the sparse far field) land on
-    // different CUs, which evens out both the work and the L2-miss queues
-    const int nb_act = (n_waves + NW - 1) / NW;            // workgroups the wave table needs
-    if ((int)blockIdx.x >= nb_act) return;                 // the rest of the (fixed, graph-captured) grid idles
-    const int wg = wave * nb_act + (int)blockIdx.x;
-    int2 chunk = make_int2(0, 0);
-    if (wg < n_waves) { const auto tb = G((const int2*)cp->wave_table); chunk.x = tb[wg].x; chunk.y = tb[wg].y; }
-    const int i = chunk.x + lane;
-    const int nq = cp->n_q;
-    const bool valid = lane < chunk.y && i < nq;
-    v4f* lpts = s_pts[wave];
-    int2* lrows = s_rows[wave];
-    uint16_t* lcand = s_cand[wave];
-
-    const GridDesc g = cp->g;
-    const auto map = G((const v4f*)cp->map_sorted);
-    const auto cell_start = G(cp->cell_start);
-    const auto prevp = G((v4f*)cp->prevp);
-    const int ablate = cp->ablate;
-    const float gatef = cp->gate_f;
-
-    // everything that does not depend on the pose is requested first: it is in flight while the
-    // previous iteration is closed below
-    float px = 0.0f, py = 0.0f, pz = 0.0f, sx = 0.0f, sy = 0.0f, sz = 0.0f;
-    v4f pm[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) pm[j] = v4f{ 0, 0, 0, 0 };
-    int pvalid = 0;
-    v4f pl_early = { 0, 0, 0, 0 };
-    int pst_early = 0;
-    if (valid) {
-#pragma unroll
-        for (int j = 0; j < 5; j++) pm[j] = prevp[(size_t)j * nq + i];
-        pvalid = G(cp->prior_valid)[i];
-        px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
-        pl_early = G((const v4f*)cp->plane_cache)[i];      // used if the neighbour tuple is unchanged
-        pst_early = G(cp->plane_state)[i];
-    }
-
-    // transPointAssociateToMap (:1069-1072) and the LM trig (:1170-1175). Launch 0 of a scan gets them
-    // from the host (libm); later launches rebuild them from the pose: lanes 0..2 take one angle each
-    // (glibc's sinf / cosf arithmetic, see glibc_sincosf).  With solve_prev the pose is first advanced by closing
-    // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.
-    float T[12], sc6[6];
-    if (!solve_prev && st->T_valid) {
-#pragma unroll
-        for (int k = 0; k < 12; k++) T[k] = st->T[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) sc6[k] = st->sc[k];
-    } else {
-        float pose[6];
-        if (solve_prev) {
-            static_assert(sizeof(LmShared) <= sizeof(v4f) * kTilePts * NW, "LM scratch must fit the tile area");
-            LmShared& sh = *reinterpret_cast<LmShared*>(&s_pts[0][0]);
-            const int degen0 = st->isDegenerate;
-            float pose0[6];
-#pragma unroll
-            for (int k = 0; k < 6; k++) pose0[k] = st->pose2[(launch - 1) & 1][k];
-            if (HOOK) lm_stamps[5] = wall_clock64();
-            const bool ended = lm_close_iteration<kBlock, false>(cp, st, nb_act, launch - 1, blockIdx.x == 0, false, pose0, degen0,
-                                                                 sh, s_lm_out, pose, HOOK ? lm_stamps : nullptr);
-            if (ended) return;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 6; k++) pose[k] = st->pose2[launch & 1][k];
-        }
-        const float ang = (lane == 0) ? pose[2] : ((lane == 1) ? pose[1] : pose[0]);   // lane 0: yaw, 1: pitch, 2+: roll
-        const float snf = glibc_sincosf(ang, 0), csf = glibc_sincosf(ang, 1);      // what the host's libm would return
-        const float B = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 0)), A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 0));
-        const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 1)), C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 1));
-        const float F = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 2)), E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 2));
-        const float DE = D * E, DF = D * F;
-        T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = pose[3];
-        T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = pose[4];
-        T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = pose[5];
-        sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
-    }
-
-    if (HOOK) lm_stamps[6] = wall_clock64();
-    Top5 best;
-#pragma unroll
-    for (int k = 0; k < 5; k++) { best.key[k] = kKeyInf; best.x[k] = 0.0f; best.y[k] = 0.0f; best.z[k] = 0.0f; }
-    float bound = gatef;
-    int pidx[5] = { -1, -1, -1, -1, -1 };
-
-    if (valid) {
-        // pointAssociateToMap (:302-308), association order of the reference expression
-        sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
-        sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
-        sz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
-#pragma unroll
-        for (int j = 0; j < 5; j++) pidx[j] = pvalid ? __float_as_int(pm[j].w) : -1;
-        if (pvalid && !(ablate & 16)) {                  // prior: 5 distinct map points
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                float d2;
-                top5_insert(best, make_key(pm[j], sx, sy, sz, d2), pm[j].x, pm[j].y, pm[j].z);
-            }
-            const float w5 = __uint_as_float((uint32_t)(best.key[4] >> 32));
-            if (w5 == w5) bound = fminf(w5, gatef);
-            else {                                       // NaN distance: drop the prior
-#pragma unroll
-                for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
-            }
-        }
-    }
-
-    // ---- wave bounding box of the transformed points (non-finite points stay out of it)
-    const bool fin = valid && (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
-    const float mnx = wave_min_f32(fin ? sx : INFINITY), mxx = wave_max_f32(fin ? sx : -INFINITY);
-    const float mny = wave_min_f32(fin ? sy : INFINITY), mxy = wave_max_f32(fin ? sy : -INFINITY);
-    const float mnz = wave_min_f32(fin ? sz : INFINITY), mxz = wave_max_f32(fin ? sz : -INFINITY);
-    const float rmax2 = wave_max_f32(fin ? bound : 0.0f);
-
-    bool certain_far = false;                             // proved: fewer than 5 map points inside the gate
-    unsigned long long clk1 = 0, clk2 = 0;
-    int dbg_mode = 0, dbg_rows = 0, dbg_pts = 0, dbg_raw = 0, dbg_why = 0, dbg_box = 0, dbg_skip = 0;
-    S2M_LAP(t_bbox);
-
-    if (mnx <= mxx && !(ablate & 8)) {                                                // wave-uniform
-        const int cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
-        const int cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
-        const int cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
-        // cell_coord is monotone: the box of the lanes' cells is the cells of the box corners
-        const int bx0 = max(cell_coord(mnx, g.ox, g.inv_e, g.nx) - 1, 0), bx1 = min(cell_coord(mxx, g.ox, g.inv_e, g.nx) + 1, g.nx - 1);
-        const int by0 = max(cell_coord(mny, g.oy, g.inv_e, g.ny) - 1, 0), by1 = min(cell_coord(mxy, g.oy, g.inv_e, g.ny) + 1, g.ny - 1);
-        const int bz0 = max(cell_coord(mnz, g.oz, g.inv_e, g.nz) - 1, 0), bz1 = min(cell_coord(mxz, g.oz, g.inv_e, g.nz) + 1, g.nz - 1);
-        const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
-        const int R = nyb * nzb;                          // rows in the box
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);      // this lane's cells in a row
-        if (HOOK) { dbg_rows = R; dbg_box = ((bx1 - bx0 + 1) << 20) | (nyb << 10) | nzb; dbg_why = 0; }
-
-        // squared slab distances of this query to the faces of its own cell: lower bounds of the
-        // distance to anything in the neighbouring row / cell on that side (see kSlabMargin)
-        const float E = g.e;
-        const float xlo = g.ox + (float)cx * E, ylo = g.oy + (float)cy * E, zlo = g.oz + (float)cz * E;
-        const float gxm = fmaxf(sx - xlo - kSlabMargin, 0.0f), gxp = fmaxf(xlo + E - sx - kSlabMargin, 0.0f);
-        const float gym = fmaxf(sy - ylo - kSlabMargin, 0.0f), gyp = fmaxf(ylo + E - sy - kSlabMargin, 0.0f);
-        const float gzm = fmaxf(sz - zlo - kSlabMargin, 0.0f), gzp = fmaxf(zlo + E - sz - kSlabMargin, 0.0f);
-        const float gx2m = gxm * gxm * 0.9999f, gx2p = gxp * gxp * 0.9999f;
-        const float gy2m = gym * gym * 0.9999f, gy2p = gyp * gyp * 0.9999f;
-        const float gz2m = gzm * gzm * 0.9999f, gz2p = gzp * gzp * 0.9999f;
-
-        // ---- tile path: per group of 64 box rows, mark the rows some lane still needs, size them
-        // and stream them through the filter into the tile; gather only if the tile overflows
-        // a box far larger than the lanes' own neighbourhoods (scattered points) is not worth staging
-        const int nfin = __popcll(__ballot(fin));
-        const int tile_cap = kTilePts;
-        const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
-        const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
-        bool glanes = false;                              // lanes that take the gather path
-        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * nfin;
-        if (HOOK && !tile) dbg_why = 1;
-        int nt = 0, ntf = 0;                              // tile fill from the front (near) and the back (far), wave-uniform
-        const float wcx = 0.5f * (mnx + mxx), wcy = 0.5f * (mny + mxy), wcz = 0.5f * (mnz + mxz);
-        const float whd = 0.5f * sqrtf(((mxx - mnx) * (mxx - mnx) + (mxy - mny) * (mxy - mny)) + (mxz - mnz) * (mxz - mnz));
-        const float near2 = (whd + 0.45f) * (whd + 0.45f);
-        for (int rg = 0; rg < R && tile; rg += 64) {
-            // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
-            unsigned long long need = 0ull;
-            if (fin) {
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int dyc = run_dy(k), dzc = run_dz(k);
-                    const int yy = cy + dyc, zz = cz + dzc;
-                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                    const int r = (zz - bz0) * nyb + (yy - by0) - rg;
-                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > bound) && r >= 0 && r < 64)
-                        need |= 1ull << r;
-                }
-            }
-            const uint32_t nlo = wave_or_u32((uint32_t)need), nhi = wave_or_u32((uint32_t)(need >> 32));
-            const bool mine = (((lane < 32) ? (nlo >> lane) : (nhi >> (lane - 32))) & 1u) != 0u;
-            int gs = 0, len = 0;                          // lane r: row rg + r of the box
-            if (mine) {                                   // whole rows: a compact wave's box is narrow in x
-                const int r = rg + lane;
-                const int zq = r / nyb;
-                const int gcell = ((bz0 + zq) * g.ny + by0 + (r - zq * nyb)) * g.nx;
-                gs = cell_start[gcell + bx0];
-                len = cell_start[gcell + bx1 + 1] - gs;
-            }
-            const int ptot = __builtin_amdgcn_readlane(wave_incl_scan_i32(len), 63);
-            if (HOOK) dbg_raw += ptot;
-            if (ptot > kTileRaw) { tile = false; if (HOOK) dbg_why = 2; break; }
-            S2M_LAP(t_mark);
-            // ---- stage through the filter: 16 lanes per row, 8 rows in flight per pass; a point
-            // enters the tile only if it lies inside the wave's point box grown by the largest bound
-            // Rows nobody marked, and marked rows that are empty, are squeezed out first (through LDS): every
-            // batch of 8 rows costs a dependent round trip to the map whatever it holds.
-            const int sub = lane >> 4, l16 = lane & 15;
-            const unsigned long long nzrows = __ballot(len > 0);
-            const int nr = __popcll(nzrows);
-            if (len > 0) lrows[__popcll(nzrows & ((1ull << lane) - 1ull))] = make_int2(gs, len);
-            wave_lds_sync();
-            for (int cb = 0; cb < nr && tile; cb += 8) {
-                const int ca = cb + sub, cc = cb + 4 + sub;
-                int gsa = 0, na = 0, gsc = 0, nn = 0;
-                if (ca < nr) { const int2 rw = lrows[ca]; gsa = rw.x; na = rw.y; }
-                if (cc < nr) { const int2 rw = lrows[cc]; gsc = rw.x; nn = rw.y; }
-                const int npass = wave_max_i32(max(na, nn));
-                for (int k0 = 0; k0 < npass; k0 += 16) {
-                    const int k = k0 + l16;
-                    v4f pa_v = { 0, 0, 0, 0 }, pc_v = { 0, 0, 0, 0 };
-                    const bool ha = k < na, hc = k < nn;
-                    if (ha) pa_v = map[gsa + k];
-                    if (hc) pc_v = map[gsc + k];
-                    const bool ia = ha && pa_v.x >= fx0 && pa_v.x <= fx1 && pa_v.y >= fy0 && pa_v.y <= fy1 && pa_v.z >= fz0 && pa_v.z <= fz1;
-                    const bool ic = hc && pc_v.x >= fx0 && pc_v.x <= fx1 && pc_v.y >= fy0 && pc_v.y <= fy1 && pc_v.z >= fz0 && pc_v.z <= fz1;
-                    // near the wave's centre -> front of the tile, the rest -> back: a full sweep then
-                    // meets every lane's likely neighbours first and its bound is tight for the remainder
-                    const float ax = pa_v.x - wcx, ay = pa_v.y - wcy, az = pa_v.z - wcz;
-                    const float bx = pc_v.x - wcx, by = pc_v.y - wcy, bz = pc_v.z - wcz;
-                    const bool na_ = (ax * ax + ay * ay) + az * az <= near2, nc_ = (bx * bx + by * by) + bz * bz <= near2;
-                    const unsigned long long man = __ballot(ia && na_), maf = __ballot(ia && !na_);
-                    const unsigned long long mcn = __ballot(ic && nc_), mcf = __ballot(ic && !nc_);
-                    const int an = __popcll(man), af = __popcll(maf), cn = __popcll(mcn), cf = __popcll(mcf);
-                    if (nt + ntf + an + af + cn + cf > tile_cap) { tile = false; if (HOOK) dbg_why = 3; break; }
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    if (ia) lpts[na_ ? nt + __popcll(man & below) : tile_cap - 1 - (ntf + __popcll(maf & below))] = pa_v;
-                    if (ic) lpts[nc_ ? nt + an + __popcll(mcn & below) : tile_cap - 1 - (ntf + af + __popcll(mcf & below))] = pc_v;
-                    nt += an + cn; ntf += af + cf;
-                }
-            }
-            S2M_LAP(t_stage);
-        }
-
-        if (tile) {
-            wave_lds_sync();
-            if (HOOK) { dbg_mode = 1; dbg_pts = nt + ntf; }
-            // ---- verify: count the tile points with d2 <= bound (branch-free, ~10 VALU a point).
-            //  - complete prior and exactly 5: no OTHER point lies within the prior's 5th distance (all 5
-            //    prior points are in the tile: their rows were marked and they pass the filter), so the
-            //    ordered neighbour set is the prior;
-            //  - bound is the gate and fewer than 5: the point is not gated, whatever its neighbours are.
-            bool todo = fin;                              // lanes that still need a sweep
-            float tb = bound;                             // radius (squared) of this lane's candidate list ...
-            int ccnt = 0;                                 // ... and the number of tile points inside it
-            if (!(ablate & 1)) {
-                const bool prior_ok = fin && best.key[4] != kKeyInf &&
-                                      __uint_as_float((uint32_t)(best.key[4] >> 32)) <= bound;
-                // A wave of a split chunk holds 32, 16 or 8 points in its first lanes; the idle lanes join
-                // in: kq = 2, 4 or 8 lanes share a point, each counts every kq-th tile point, and the
-                // partial counts are added across the group.  (These short waves are the ones in dense
-                // parts of the map, i.e. the slowest of a launch.)
-                // `cold`: some lane has no usable prior (first launch of a scan, or the prior was lost).  Its
-                // bound is the gate, and a candidate list cut at the gate could be long; so the sweep counts
-                // against four radii at once (bound, /2, /4, /8) and each lane keeps the tightest one that
-                // still holds 5 points: tb, with ccnt points inside.
-                const bool cold = __ballot(fin && !prior_ok) != 0ull;
-                const int kq = cold ? 1 : ((chunk.y > 32) ? 1 : ((chunk.y > 16) ? 2 : ((chunk.y > 8) ? 4 : 8)));
-                const int nslot = 64 / kq, part = lane / nslot;
-                float qx_ = sx, qy_ = sy, qz_ = sz, qb_ = bound;
-                if (kq > 1) {
-                    const int src = lane & (nslot - 1);
-                    qx_ = __shfl(sx, src, 64); qy_ = __shfl(sy, src, 64); qz_ = __shfl(sz, src, 64); qb_ = __shfl(bound, src, 64);
-                }
-                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                if (cold) {
-                    const float t1 = bound * 0.5f, t2 = bound * 0.25f, t3 = bound * 0.125f;
-                    for (int seg = 0; seg < 2; seg++) {
-                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                        int j = jb;
-                        for (; j + 4 <= je; j += 4) {         // four LDS reads in flight
-                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                            float d0, d1, d2v, d3;
-                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                            c0 += ((d0 <= bound) ? 1 : 0) + ((d1 <= bound) ? 1 : 0) + ((d2v <= bound) ? 1 : 0) + ((d3 <= bound) ? 1 : 0);
-                            c1 += ((d0 <= t1) ? 1 : 0) + ((d1 <= t1) ? 1 : 0) + ((d2v <= t1) ? 1 : 0) + ((d3 <= t1) ? 1 : 0);
-                            c2 += ((d0 <= t2) ? 1 : 0) + ((d1 <= t2) ? 1 : 0) + ((d2v <= t2) ? 1 : 0) + ((d3 <= t2) ? 1 : 0);
-                            c3 += ((d0 <= t3) ? 1 : 0) + ((d1 <= t3) ? 1 : 0) + ((d2v <= t3) ? 1 : 0) + ((d3 <= t3) ? 1 : 0);
-                        }
-                        for (; j < je; j++) {
-                            float d; make_key(lpts[j], sx, sy, sz, d);
-                            c0 += (d <= bound) ? 1 : 0; c1 += (d <= t1) ? 1 : 0; c2 += (d <= t2) ? 1 : 0; c3 += (d <= t3) ? 1 : 0;
-                        }
-                    }
-                    tb = (c3 >= 5) ? t3 : ((c2 >= 5) ? t2 : ((c1 >= 5) ? t1 : bound));
-                    ccnt = (c3 >= 5) ? c3 : ((c2 >= 5) ? c2 : ((c1 >= 5) ? c1 : c0));
-                    c1 = 0; c2 = 0; c3 = 0;               // c0 = points inside `bound`, as in the other branches
-                } else if (kq == 1) {                     // the common case, with compile-time LDS offsets
-                    for (int seg = 0; seg < 2; seg++) {
-                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                        int j = jb;
-                        for (; j + 4 <= je; j += 4) {
-                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                            float d0, d1, d2v, d3;
-                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                            c0 += (d0 <= bound) ? 1 : 0; c1 += (d1 <= bound) ? 1 : 0;
-                            c2 += (d2v <= bound) ? 1 : 0; c3 += (d3 <= bound) ? 1 : 0;
-                        }
-                        for (; j < je; j++) { float d; make_key(lpts[j], sx, sy, sz, d); c0 += (d <= bound) ? 1 : 0; }
-                    }
-                } else {
-                    for (int seg = 0; seg < 2; seg++) {
-                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                        int j = jb + part;
-                        for (; j + 3 * kq < je; j += 4 * kq) {
-                            const v4f m0 = lpts[j], m1 = lpts[j + kq], m2 = lpts[j + 2 * kq], m3 = lpts[j + 3 * kq];
-                            float d0, d1, d2v, d3;
-                            make_key(m0, qx_, qy_, qz_, d0); make_key(m1, qx_, qy_, qz_, d1);
-                            make_key(m2, qx_, qy_, qz_, d2v); make_key(m3, qx_, qy_, qz_, d3);
-                            c0 += (d0 <= qb_) ? 1 : 0; c1 += (d1 <= qb_) ? 1 : 0;
-                            c2 += (d2v <= qb_) ? 1 : 0; c3 += (d3 <= qb_) ? 1 : 0;
-                        }
-                        for (; j < je; j += kq) { float d; make_key(lpts[j], qx_, qy_, qz_, d); c0 += (d <= qb_) ? 1 : 0; }
-                    }
-                }
-                int cnt = c0 + c1 + c2 + c3;
-                for (int m = nslot; m < 64; m <<= 1) cnt += __shfl_xor(cnt, m, 64);
-                if (!cold) ccnt = cnt;
-                if (prior_ok && cnt == 5) todo = false;
-                else if (fin && bound >= gatef && cnt < 5) { todo = false; certain_far = true; }
-            }
-            // ---- lanes with a new, lost or missing neighbour.  The insertion network costs ~45 VALU and a wave
-            // pays it whenever ANY lane inserts, i.e. at nearly every tile point; so the lanes first write down
-            // the tile positions inside tb (a second branch-free sweep; exactly ccnt of them, >= 5 by
-            // construction, so the 5 nearest are among them) and then insert their k-th candidates together:
-            // ~10 wave-wide insertions instead of one per tile point.
-            if (!(ablate & 1) && __ballot(todo)) {
-                const bool use_list = todo && ccnt <= kCand;
-                if (__ballot(use_list)) {
-                    int cc = 0;
-                    if (use_list) {
-                        for (int seg = 0; seg < 2; seg++) {
-                            const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                            int j = jb;
-                            for (; j + 4 <= je; j += 4) {     // four LDS reads in flight
-                                const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                                float d0, d1, d2v, d3;
-                                make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                                make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                                if (d0 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
-                                if (d1 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 1); cc++; }
-                                if (d2v <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 2); cc++; }
-                                if (d3 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 3); cc++; }
-                            }
-                            for (; j < je; j++) {
-                                float d; make_key(lpts[j], sx, sy, sz, d);
-                                if (d <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
-                            }
-                        }
-                    }
-                    wave_lds_sync();
-                    const int cmax = wave_max_i32(cc);
-                    // candidate k+1 is fetched while candidate k is inserted; slots past cc hold stale positions (clamped, unused)
-                    v4f mk = lpts[min((int)lcand[lane], kTilePts - 1)];
-                    for (int k = 0; k < cmax; k++) {
-                        const v4f mn_ = lpts[min((int)lcand[min(k + 1, kCand - 1) * 64 + lane], kTilePts - 1)];
-                        if (k < cc) consider(best, bound, gatef, mk, sx, sy, sz);
-                        mk = mn_;
-                    }
-                    todo = todo && !use_list;
-                }
-            }
-            // ---- full sweep for whoever is left (a candidate list that would not fit): the tile, near segment first
-            if (!(ablate & 1) && __ballot(todo)) {
-                if (todo) {
-                    for (int seg = 0; seg < 2; seg++) {
-                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                        int j = jb;
-                        for (; j + 4 <= je; j += 4) {
-                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                            consider(best, bound, gatef, m0, sx, sy, sz);
-                            consider(best, bound, gatef, m1, sx, sy, sz);
-                            consider(best, bound, gatef, m2, sx, sy, sz);
-                            consider(best, bound, gatef, m3, sx, sy, sz);
-                        }
-                        for (; j < je; j++) consider(best, bound, gatef, lpts[j], sx, sy, sz);
-                    }
-                }
-                if (HOOK) dbg_skip = __popcll(__ballot(todo));
-            }
-            S2M_LAP(t_search);
-        }
-        if (!tile) glanes = fin;
-        if (__ballot(glanes)) {
-            if (HOOK) dbg_mode = tile ? 3 : 2;
-            // ---- gather: run bounds of all 9 rows first (independent loads, kept in LDS), then the runs
-            int32_t (*lrun)[64] = reinterpret_cast<int32_t (*)[64]>(s_pts[wave]);
-            if (glanes && !(ablate & 1)) {
-                int rs[9], re[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int dyc = run_dy(k), dzc = run_dz(k);
-                    const int yy = cy + dyc, zz = cz + dzc;
-                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                    rs[k] = 0; re[k] = 0;
-                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > bound)) {
-                        const int xs = (x0 < cx && lb + gx2m <= bound) ? x0 : cx;     // left cell still reachable?
-                        const int xe = (x1 > cx && lb + gx2p <= bound) ? x1 : cx;     // right cell?
-                        const int rb = (zz * g.ny + yy) * g.nx;
-                        rs[k] = cell_start[rb + xs];
-                        re[k] = cell_start[rb + xe + 1];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) { lrun[2 * k][lane] = rs[k]; lrun[2 * k + 1][lane] = re[k]; }
-            }
-            wave_lds_sync();
-            if (glanes && !(ablate & 1)) {
-                // ---- verify first (same argument as in the tile path): count this lane's candidates
-                // with d2 <= bound, branch-free; a complete prior and a count of 5 settle the lane.
-                // The first 4 points of run k+1 are in flight while run k is counted.
-                bool full_pass = true;
-                {
-                    const bool prior_ok = best.key[4] != kKeyInf && __uint_as_float((uint32_t)(best.key[4] >> 32)) <= bound;
-                    int cnt = 0;
-                    int jn = lrun[0][lane], en = lrun[1][lane];
-                    v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
-                    if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-#pragma unroll 1
-                    for (int k = 0; k < 9; k++) {
-                        const int j0 = jn, e = en;
-                        const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
-                        if (k < 8) {
-                            jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
-                            if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-                        }
-                        if (j0 < e) {
-                            float d0, d1, d2v, d3;
-                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                            cnt += (d0 <= bound) ? 1 : 0;
-                            cnt += (j0 + 1 < e && d1 <= bound) ? 1 : 0;          // past the end the last point was re-read
-                            cnt += (j0 + 2 < e && d2v <= bound) ? 1 : 0;
-                            cnt += (j0 + 3 < e && d3 <= bound) ? 1 : 0;
-                            if (HOOK) dbg_pts += e - j0;
-                            for (int j = j0 + 4; j < e; j += 4) {                  // long runs: 4 loads in flight
-                                const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
-                                make_key(q0, sx, sy, sz, d0); make_key(q1, sx, sy, sz, d1);
-                                make_key(q2, sx, sy, sz, d2v); make_key(q3, sx, sy, sz, d3);
-                                cnt += (d0 <= bound) ? 1 : 0;
-                                cnt += (j + 1 < e && d1 <= bound) ? 1 : 0;
-                                cnt += (j + 2 < e && d2v <= bound) ? 1 : 0;
-                                cnt += (j + 3 < e && d3 <= bound) ? 1 : 0;
-                            }
-                        }
-                    }
-                    if (prior_ok && cnt == 5) full_pass = false;
-                    else if (bound >= gatef && cnt < 5) { full_pass = false; certain_far = true; }
-                }
-                // ---- full pass for the lanes that gained, lost or lack a neighbour (lines now L2-warm)
-                if (full_pass) {
-                    int jn = lrun[0][lane], en = lrun[1][lane];
-                    v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
-                    if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-#pragma unroll 1
-                    for (int k = 0; k < 9; k++) {
-                        const int j0 = jn, e = en;
-                        const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
-                        if (k < 8) {
-                            jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
-                            if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-                        }
-                        const int dyc = run_dy(k), dzc = run_dz(k);
-                        const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                        if (j0 < e && !(lb > bound)) {                                 // bound may have tightened meanwhile
-                            consider(best, bound, gatef, m0, sx, sy, sz);
-                            consider(best, bound, gatef, m1, sx, sy, sz);
-                            consider(best, bound, gatef, m2, sx, sy, sz);
-                            consider(best, bound, gatef, m3, sx, sy, sz);
-                            for (int j = j0 + 4; j < e; j += 4) {                      // long runs: 4 loads in flight
-                                const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
-                                consider(best, bound, gatef, q0, sx, sy, sz);
-                                consider(best, bound, gatef, q1, sx, sy, sz);
-                                consider(best, bound, gatef, q2, sx, sy, sz);
-                                consider(best, bound, gatef, q3, sx, sy, sz);
-                            }
-                        }
-                    }
-                }
-            }
-            S2M_LAP(t_stage);
-            S2M_LAP(t_search);
-        }
-    }
-
-    if (HOOK) clk1 = wall_clock64();
-    double acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) acc[k] = 0.0;
-
-    if (valid) {
-        // this launch's neighbours are the next launch's prior (only a complete set is usable)
-        const bool full = best.key[4] != kKeyInf;
-        bool same = full;
-#pragma unroll
-        for (int j = 0; j < 5; j++) same = same && ((int32_t)(uint32_t)(best.key[j] & 0xffffffffu) == pidx[j]);
-        if (!same) {
-            if (full) {
-#pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    const v4f o = { best.x[j], best.y[j], best.z[j], __int_as_float((int32_t)(uint32_t)(best.key[j] & 0xffffffffu)) };
-                    prevp[(size_t)j * nq + i] = o;
-                }
-            }
-            G(cp->prior_valid)[i] = full ? 1 : 0;
-        }
-
-        const float d2_4 = __uint_as_float((uint32_t)(best.key[4] >> 32));
-        const bool near5 = (double)d2_4 < cp->gate_sq;                              // :1097
-        const bool gated = near5 && !certain_far && !(ablate & 2);
-        bool keep = false;
-        float cf[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-        if (gated) {
-            // The LS plane and its inlier test depend only on the ordered neighbour tuple, not on
-            // the pose: a point that kept its 5 neighbours re-uses last launch's plane bit for bit.
-            const auto pcache = G((v4f*)cp->plane_cache);
-            const auto pstate = G(cp->plane_state);
-            float pa, pb, pc, pd;
-            bool planeValid;
-            const int pst = (same && !(ablate & 32)) ? pst_early : 0;
-            if (pst != 0) {
-                const v4f pl = pl_early;
-                pa = pl.x; pb = pl.y; pc = pl.z; pd = pl.w; planeValid = (pst == 1);
-            } else {
-                float qr[5][3];
-#pragma unroll
-                for (int j = 0; j < 5; j++) { qr[j][0] = best.x[j]; qr[j][1] = best.y[j]; qr[j][2] = best.z[j]; }   // :1099-1101
-                float X[3];
-                plane_fit_5x3(qr, X);                                                // :1104
-                pa = X[0]; pb = X[1]; pc = X[2]; pd = 1.0f;
-                const float ps = sqrtf(pa * pa + pb * pb + pc * pc);                  // :1111
-                pa /= ps; pb /= ps; pc /= ps; pd /= ps;
-                planeValid = true;
-#pragma unroll
-                for (int j = 0; j < 5; j++) {                                        // :1115-1122
-                    const float r = pa * best.x[j] + pb * best.y[j] + pc * best.z[j] + pd;
-                    if ((double)fabsf(r) > cp->plane_tol) planeValid = false;
-                }
-                const v4f pl = { pa, pb, pc, pd };
-                pcache[i] = pl;
-                pstate[i] = planeValid ? 1 : 2;
-            }
-            if (planeValid) {
-                const float pd2 = pa * sx + pb * sy + pc * sz + pd;                   // :1125
-                const float rr = sqrtf(sqrtf(px * px + py * py + pz * pz));
-                const float sw = (float)(1.0 - cp->weight_scale * (double)fabsf(pd2) / (double)rr);   // :1127
-                if ((double)sw > cp->weight_min) {                                    // :1135
-                    cf[0] = sw * pa; cf[1] = sw * pb; cf[2] = sw * pc; cf[3] = sw * pd2;              // :1130-1133
-                    keep = true;
-                }
-            }
-        } else if (!same) {
-            G(cp->plane_state)[i] = 0;
-        }
-
-        if (keep) {
-            float row[6], rhs;
-            jacobian_row(sc6, px, py, pz, cf, row, rhs);
-            int k = 0;
-#pragma unroll
-            for (int a = 0; a < 6; a++)
-#pragma unroll
-                for (int b = a; b < 6; b++) acc[k++] = (double)row[a] * (double)row[b];
-#pragma unroll
-            for (int a = 0; a < 6; a++) acc[21 + a] = (double)row[a] * (double)rhs;
-            acc[27] = 1.0;
-        }
-
-        if (HOOK) {
-            const int o = G(cp->qperm)[i];
-            if (cp->dbg_idx5) {
-#pragma unroll
-                for (int j = 0; j < 5; j++) G(cp->dbg_idx5)[5 * (size_t)o + j] = gated ? (int32_t)(uint32_t)(best.key[j] & 0xffffffffu) : -1;
-            }
-            if (cp->dbg_d2) {
-#pragma unroll
-                for (int j = 0; j < 5; j++) G(cp->dbg_d2)[5 * (size_t)o + j] = __uint_as_float((uint32_t)(best.key[j] >> 32));
-            }
-            if (cp->dbg_flag) G(cp->dbg_flag)[o] = keep ? 1 : 0;
-            if (cp->dbg_coeff) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) G(cp->dbg_coeff)[4 * (size_t)o + j] = cf[j];
-            }
-        }
-    }
-
-    if (HOOK) { if (dbg_mode != 1) dbg_skip = wave_max_i32((dbg_mode >= 2) ? dbg_pts : 0); clk2 = wall_clock64(); }
-    // ---- wave reduction by recursive halving: at mask m a lane keeps one half of its sums and
-    // hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
-    // five steps lane l holds, in acc[0], sum number l>>1 over its half-wave pair group, and one
-    // full exchange with lane^1 completes it.  Fixed order: bitwise reproducible.
-    const auto partial_row = G(cp->partials) + ((size_t)(launch & 1) * (size_t)cp->nblocks + blockIdx.x) * kAcc;   // slot launch & 1
-    if (ablate & 4) { if (tid < kAcc) partial_row[tid] = acc[0] + acc[27]; return; }
-#pragma unroll
-    for (int h = 16, m = 32; h >= 1; h >>= 1, m >>= 1) {
-        const bool up = (lane & m) != 0;
-#pragma unroll
-        for (int j = 0; j < h; j++) {
-            const double keepv = up ? acc[j + h] : acc[j];
-            const double sendv = up ? acc[j] : acc[j + h];
-            acc[j] = keepv + __shfl_xor(sendv, m, 64);
-        }
-    }
-    acc[0] += __shfl_xor(acc[0], 1, 64);
-    if ((lane & 1) == 0) red[wave][lane >> 1] = acc[0];
-    if (HOOK && cp->dbg_clk && lane == 0) {
-        const auto d = G(cp->dbg_clk) + kProfWords * ((size_t)blockIdx.x * NW + wave);
-        d[0] = tk_start; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
-        d[4] = (unsigned long long)dbg_mode; d[5] = (unsigned long long)dbg_rows; d[6] = (unsigned long long)dbg_pts; d[7] = (unsigned long long)dbg_raw;
-        d[8] = t_bbox; d[9] = t_mark; d[10] = (unsigned long long)chunk.y; d[11] = t_stage; d[12] = t_search; d[13] = (unsigned long long)dbg_why; d[14] = (unsigned long long)dbg_box; d[15] = (unsigned long long)dbg_skip;
-        // fused LM close (solve_prev launches): entry, partial sums reduced, normal equations, QR, update, barrier, T built
-        d[16] = lm_stamps[5]; d[17] = lm_stamps[0]; d[18] = lm_stamps[1]; d[19] = lm_stamps[2]; d[20] = lm_stamps[3]; d[21] = lm_stamps[4]; d[22] = lm_stamps[6]; d[23] = 0;
-    }
-    __syncthreads();
-    if (tid < kAcc) {
-        double s = red[0][tid];
-#pragma unroll
-        for (int w = 1; w < NW; w++) s += red[w][tid];
-        partial_row[tid] = s;
-    }
-#undef S2M_LAP
-}
+#include "s2m_register.hpp"
 
 // ------------------------------------------------------------------------------------------
 // k_finalize: one workgroup closing iteration `iter` on its own (lm_close_iteration above):

@@ -1,0 +1,1099 @@
+// s2m_register.hpp — k_register, the registration kernel: one launch = one surfOptimization() pass
+// (reference src/mapOptmization.cpp:1074-1143) fused with the matA/matB row assembly of LMOptimization()
+// (:1191-1235) and the first stage of the AtA / AtB reduction (:1237-1239); in the fused loop its
+// prologue also closes the previous LM iteration (lm_close_iteration).  Included by s2m_kernels.hpp.
+//
+// What the reference recomputes 30 times per scan, and what actually changes
+// ---------------------------------------------------------------------------
+// The LM loop revisits the same scan with an ever smaller pose step.  surfOptimization() redoes the
+// 5-NN search, the plane fit and the inlier test for every point in every iteration, although for
+// nearly every point the ORDERED neighbour tuple - and with it the plane, which depends on nothing
+// else - is the same as in the iteration before.  This kernel keeps, per scan point, what it needs to
+// PROVE that, and touches the map only for the points where the proof fails:
+//
+//   tier A  certificate.  When a point's tuple (n1..n5, ascending (d2, map index)) is established at
+//           the transformed position q_ref, the kernel also knows r6: no other map point was nearer
+//           than r6.  With d1..d5 the tuple's distances, let
+//               slack = min( (d2-d1)/2, .., (d5-d4)/2, (r6-d5)/2, gate-d5 ) - margin.
+//           At a later pose the point stands at q with e = |q - q_ref|.  Every distance changed by at
+//           most e (triangle inequality), so while e < slack the order of n1..n5 is the same, every
+//           other map point is still farther than n5, and d5 is still inside the gate (:1097): same
+//           tuple, same plane, same inlier verdict - bit for bit what a fresh search would return,
+//           without reading a single map point.  A point with fewer than 5 map points inside the
+//           gate carries the mirror image: slack = r6 - gate - margin, "still not gated".
+//           The margin (2 um) is twenty times the fp32 rounding of the distance arithmetic (1e-7 relative
+//           on distances below 1 m; the triangle inequality itself is exact for the rounded positions the
+//           reference measures from); tuples with an exact tie (gap 0) never get a certificate.
+//   tier B  re-measure.  A point that moved farther than its slack fetches its 5 stored neighbours
+//           (by position in the cell-sorted map) and measures them again.  If the new 5th distance is
+//           still below r6 - e, the SET is unchanged; order, gate and slack are refreshed, the plane is
+//           refitted only if the order changed.
+//   tier C  search.  Only the lanes that fail A and B search: the tile path (compact waves: box rows
+//           staged through a filter into the wave's LDS tile, count verification against the re-measured
+//           tuple's 5th distance, candidate lists, wave-wide insertion) or, when a handful of lanes is
+//           left or the wave is scattered, the gather path (each lane walks the <= 9 x-runs of its own
+//           3x3x3 cells in the L2-resident map).  The search looks kCertDelta beyond the 5th distance so
+//           that the count sweep, which sees every point there anyway, also yields r6 for the next
+//           certificate.  Search keys are (fp32 d2 bits << 32 | map position): one 64-bit compare orders
+//           them, and the position fetches coordinates and the original map index afterwards.  The
+//           reference order (d2, original index) differs from (d2, position) only between points at exactly
+//           equal distance: ties inside the tuple are re-ordered after the fetch, a tie across the 5th/6th
+//           boundary is detected during insertion and settled by an exact walk over the lane's cells.
+//
+// In the steady state of the loop (pose steps of 1e-4 m and less) nearly every wave is all tier A: it
+// reads 44 bytes per point (position, certificate, plane) and no map data at all.
+//
+// Two passes per wave, so that the 28 fp64 sums of the normal equations never coexist with the search's
+// registers:  pass 1 (associate) brings every point's tuple / plane / certificate up to date for this
+// pose;  pass 2 (linearise) streams position + plane: residual, weight (:1125-1139), Jacobian row
+// (:1216-1234), 21+6+1 products accumulated in fp64.  A wave loops over wave-table entries (stride =
+// waves in the grid), so the grid never exceeds kMaxBlocks co-resident workgroups whatever the scan
+// size, and the accumulators are reduced once per wave: recursive halving over the lanes, LDS across
+// the 8 waves, one partial row per workgroup in the slot of this launch's parity.
+// combineOptimizationCoeffs() (:1145-1156) has no counterpart: rejected lanes add zeros.
+#pragma once
+// (included inside namespace s2m by s2m_kernels.hpp)
+
+constexpr float kCertMargin = 2e-6f;   // metres; see tier A above
+constexpr float kCertDelta  = 0.04f;   // metres the search looks beyond the 5th neighbour for the 6th
+constexpr int   kGatherLanes = 8;      // up to this many searching lanes are served one by one instead of staging a tile
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t key_hi(uint64_t k) { return (uint32_t)(k >> 32); }
+__device__ __forceinline__ uint32_t key_lo(uint64_t k) { return (uint32_t)k; }
+__device__ __forceinline__ void cas_u64(uint64_t& a, uint64_t& b)
+{
+    const bool c = b < a;
+    const uint64_t t = a;
+    a = c ? b : a; b = c ? t : b;
+}
+// 5 keys, ascending: the 9-comparator network
+__device__ __forceinline__ void sort5_u64(uint64_t (&k)[5])
+{
+    cas_u64(k[0], k[1]); cas_u64(k[3], k[4]); cas_u64(k[2], k[4]); cas_u64(k[2], k[3]); cas_u64(k[1], k[4]);
+    cas_u64(k[0], k[3]); cas_u64(k[0], k[2]); cas_u64(k[1], k[3]); cas_u64(k[1], k[2]);
+}
+
+// exact top-5 of the search: key = (fp32 d2 bits << 32) | position in map_sorted, ascending
+struct Top5k { uint64_t key[5]; };
+
+__device__ __forceinline__ void top5k_insert(Top5k& t, uint64_t key)
+{
+    t.key[4] = key;
+#pragma unroll
+    for (int j = 4; j > 0; --j) cas_u64(t.key[j - 1], t.key[j]);
+}
+
+// m = {x, y, z, low word of the key}: a tile entry carries the map position there, a map_sorted entry the original index
+__device__ __forceinline__ uint64_t make_key(const v4f m, float sx, float sy, float sz, float& d2)
+{
+    const float dx = sx - m.x, dy = sy - m.y, dz = sz - m.z;
+    d2 = (dx * dx + dy * dy) + dz * dz;                                               // L2_Simple order
+    return ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)__float_as_int(m.w);
+}
+
+// bound = min(d2 of the current 5th best, gate): nothing at or beyond the gate is observable.
+// tieb remembers the d2 bits of a point that was met at exactly the 5th best's distance: if that is still the
+// 5th distance at the end, (d2, position) and (d2, original index) may disagree about who is fifth.
+__device__ __forceinline__ void consider(Top5k& best, float& bound, float gatef, uint32_t& tieb, const v4f m, float sx, float sy, float sz)
+{
+    float d2;
+    const uint64_t key = make_key(m, sx, sy, sz, d2);
+    const uint32_t pos = key_lo(key), d2b = key_hi(key);
+    // one straight-line predicate, one branch.  A map point already in the set (the stored tuple's points are met
+    // again; the gather path re-reads the last point of a run) has the same position.
+    const bool fresh = (pos != key_lo(best.key[0])) & (pos != key_lo(best.key[1])) & (pos != key_lo(best.key[2])) & (pos != key_lo(best.key[3]));
+    const bool inb = d2 <= bound;
+    const bool tie = inb & fresh & (d2b == key_hi(best.key[4])) & (pos != key_lo(best.key[4]));
+    tieb = tie ? d2b : tieb;
+    if (inb & fresh & (key < best.key[4])) {
+        const uint32_t out5 = key_hi(best.key[4]);        // the point this insertion pushes out of the set ...
+        top5k_insert(best, key);
+        tieb = (out5 == key_hi(best.key[4])) ? out5 : tieb;   // ... may stand at exactly the new 5th distance
+        bound = fminf(__uint_as_float(key_hi(best.key[4])), gatef);
+    }
+}
+
+// The exact walk that settles a tie across the 5th/6th boundary (rare: two map points at bit-identical distance):
+// the lane's 3x3x3 cells, keys (d2, ORIGINAL index), positions carried along.  Result as (d2 | position) keys in the
+// reference order.
+__device__ __forceinline__ void exact_top5_of_cells(gptr<const v4f> map, gptr<const int32_t> cell_start, const GridDesc& g,
+                                                    int cx, int cy, int cz, float sx, float sy, float sz, float gatef, Top5k& out)
+{
+    uint64_t ek[5];
+    int ep[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) { ek[k] = kKeyInf; ep[k] = 0x7fffffff; }
+    float bound = gatef;
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+        const int yy = cy + run_dy(k), zz = cz + run_dz(k);
+        if (yy < 0 || yy >= g.ny || zz < 0 || zz >= g.nz) continue;
+        const int rb = (zz * g.ny + yy) * g.nx;
+        const int js = cell_start[rb + max(cx - 1, 0)], je = cell_start[rb + min(cx + 1, g.nx - 1) + 1];
+#pragma unroll 1
+        for (int j = js; j < je; j++) {
+            float d2;
+            const uint64_t key = make_key(map[j], sx, sy, sz, d2);
+            if (d2 <= bound && key < ek[4]) {
+                ek[4] = key; ep[4] = j;
+#pragma unroll
+                for (int q = 4; q > 0; --q) {
+                    const bool c = ek[q] < ek[q - 1];
+                    const uint64_t tk = ek[q - 1]; ek[q - 1] = c ? ek[q] : tk; ek[q] = c ? tk : ek[q];
+                    swap_if(c, ep[q - 1], ep[q]);
+                }
+                bound = fminf(__uint_as_float(key_hi(ek[4])), gatef);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) out.key[k] = (ek[k] == kKeyInf) ? kKeyInf : (((uint64_t)key_hi(ek[k]) << 32) | (uint32_t)ep[k]);
+}
+
+// per-wave diagnostics of the hook variant
+struct WaveProf {
+    int mode = 0;              // search path taken by the last entry that searched: 1 tile, 2 gather, 3 tile then gather
+    int n_a = 0, n_b = 0, n_c = 0;   // lanes settled by certificate / by re-measuring / by searching (summed over the wave's entries)
+    int rows = 0, pts = 0, raw = 0, why = 0;
+};
+
+// ------------------------------------------------------------------------------------------
+// pass 1: bring tuple / plane / certificate of the points of one wave-table entry up to date
+// ------------------------------------------------------------------------------------------
+template <bool HOOK>
+__device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, const GridDesc& g, gptr<const v4f> map,
+                                                gptr<const int32_t> cell_start, const float (&T)[12], float gatef, int ablate,
+                                                int2 chunk, int lane, v4f* lpts, int2* lrows, uint16_t* lcand,
+                                                float px, float py, float pz, v4f cert, WaveProf& prof)
+{
+    const int nq = cp->n_q;
+    const int i = chunk.x + lane;
+    const bool valid = lane < chunk.y && i < nq;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f;
+    if (valid) {
+        // pointAssociateToMap (:302-308), association order of the reference expression
+        sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
+        sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
+        sz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
+    }
+    const bool fin = valid && (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
+
+    // ---- tier A: has the point moved less than its slack since its tuple was established?
+    const float ex = sx - cert.x, ey = sy - cert.y, ez = sz - cert.z;
+    const float eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
+    const bool passA = fin && !(ablate & 1) && (eps < cert.w);          // slack 0 (no certificate) and NaN never pass
+    const bool need = fin && !passA;
+    if (HOOK) prof.n_a += __popcll(__ballot(passA));
+    if (!HOOK && !__ballot(need)) return;                                // the whole entry is certified
+
+    // ---- tier B: re-measure the stored tuple
+    const auto auxp = G((v2i*)cp->aux);
+    const auto nposp = G(cp->npos);
+    const auto certp = G((v4f*)cp->cert);
+    const auto planep = G((v4f*)cp->plane_cache);
+    const bool lookB = HOOK ? fin : need;
+    int ost = 0;
+    float r6o = 0.0f;
+    int opos[5] = { 0, 0, 0, 0, 0 };
+    if (lookB) {
+        const v2i a = auxp[i];
+        r6o = __int_as_float(a.x); ost = a.y;
+#pragma unroll
+        for (int j = 0; j < 5; j++) opos[j] = nposp[(size_t)j * nq + i];
+    }
+    const bool had5 = lookB && (ost & 4) != 0;
+    uint64_t sk[5];                                                      // the stored tuple at this pose: (d2 | position), re-sorted
+    {
+        v4f nb[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) nb[j] = map[had5 ? opos[j] : 0];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            float d2;
+            make_key(nb[j], sx, sy, sz, d2);
+            sk[j] = had5 ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)opos[j]) : kKeyInf;
+        }
+        if (HOOK && valid && passA) {
+            // certified lanes report the stored tuple in the STORED order with the distances measured now: a wrong
+            // certificate shows up in the parity tests as a mis-ordered or wrong neighbour list
+            const int o = G(cp->qperm)[i];
+            const bool gatedA = (ost & 3) != 0;
+            if (cp->dbg_idx5) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) G(cp->dbg_idx5)[5 * (size_t)o + j] = gatedA ? __float_as_int(nb[j].w) : -1;
+            }
+            if (cp->dbg_d2) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) G(cp->dbg_d2)[5 * (size_t)o + j] = gatedA ? __uint_as_float(key_hi(sk[j])) : INFINITY;
+            }
+        }
+    }
+    sort5_u64(sk);
+    const bool meas_ok = had5 && key_hi(sk[4]) < 0x7f800000u;          // five finite distances
+    bool passB = false;
+    {
+        const float d2_5 = __uint_as_float(key_hi(sk[4]));
+        const float d5n = sqrtf(d2_5), r6n = r6o - eps;
+        passB = need && meas_ok && !(ablate & 2) && (d5n + kCertMargin < r6n) && ((double)d2_5 < cp->gate_sq);
+    }
+    const bool needC = need && !passB;
+    if (HOOK) { prof.n_b += __popcll(__ballot(passB)); prof.n_c += __popcll(__ballot(needC)); }
+
+    // ---- tier C: search, for the lanes that are left
+    Top5k best;
+#pragma unroll
+    for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
+    float bound = gatef;
+    float r6sq = 0.0f;                 // squared: no map point outside the final tuple is nearer than this (0: unknown)
+    bool far = false;                  // proved: fewer than 5 map points inside the gate
+    const unsigned long long cmask = __ballot(needC);
+    if (cmask) {
+        uint32_t tieb = 0xffffffffu;
+        if (needC && meas_ok && !(ablate & 16)) {                        // the re-measured tuple: 5 distinct map points, a valid upper bound
+#pragma unroll
+            for (int k = 0; k < 5; k++) best.key[k] = sk[k];
+            bound = fminf(__uint_as_float(key_hi(sk[4])), gatef);
+        }
+        const int nC = __popcll(cmask);
+        // wave bounding box of the searching lanes
+        const float mnx = wave_min_f32(needC ? sx : INFINITY), mxx = wave_max_f32(needC ? sx : -INFINITY);
+        const float mny = wave_min_f32(needC ? sy : INFINITY), mxy = wave_max_f32(needC ? sy : -INFINITY);
+        const float mnz = wave_min_f32(needC ? sz : INFINITY), mxz = wave_max_f32(needC ? sz : -INFINITY);
+
+        const int cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
+        const int cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
+        const int cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
+        // cell_coord is monotone: the box of the lanes' cells is the cells of the box corners
+        const int bx0 = max(cell_coord(mnx, g.ox, g.inv_e, g.nx) - 1, 0), bx1 = min(cell_coord(mxx, g.ox, g.inv_e, g.nx) + 1, g.nx - 1);
+        const int by0 = max(cell_coord(mny, g.oy, g.inv_e, g.ny) - 1, 0), by1 = min(cell_coord(mxy, g.oy, g.inv_e, g.ny) + 1, g.ny - 1);
+        const int bz0 = max(cell_coord(mnz, g.oz, g.inv_e, g.nz) - 1, 0), bz1 = min(cell_coord(mxz, g.oz, g.inv_e, g.nz) + 1, g.nz - 1);
+        const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
+        const int R = nyb * nzb;                          // rows in the box
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);      // this lane's cells in a row
+        if (HOOK) { prof.rows = R; prof.why = 0; }
+
+        // squared slab distances of this query to the faces of its own cell: lower bounds of the
+        // distance to anything in the neighbouring row / cell on that side (see kSlabMargin)
+        const float E = g.e;
+        const float xlo = g.ox + (float)cx * E, ylo = g.oy + (float)cy * E, zlo = g.oz + (float)cz * E;
+        const float gxm = fmaxf(sx - xlo - kSlabMargin, 0.0f), gxp = fmaxf(xlo + E - sx - kSlabMargin, 0.0f);
+        const float gym = fmaxf(sy - ylo - kSlabMargin, 0.0f), gyp = fmaxf(ylo + E - sy - kSlabMargin, 0.0f);
+        const float gzm = fmaxf(sz - zlo - kSlabMargin, 0.0f), gzp = fmaxf(zlo + E - sz - kSlabMargin, 0.0f);
+        const float gx2m = gxm * gxm * 0.9999f, gx2p = gxp * gxp * 0.9999f;
+        const float gy2m = gym * gym * 0.9999f, gy2p = gyp * gyp * 0.9999f;
+        const float gz2m = gzm * gzm * 0.9999f, gz2p = gzp * gzp * 0.9999f;
+        // How far this lane looks: kCertDelta beyond its bound, but not beyond what its 3x3x3 cells cover for certain
+        // (one whole cell past the nearest face of its own cell).  Every map point nearer than `be` is met.
+        const float cover = (E - kSlabMargin) + fminf(fminf(fminf(gxm, gxp), fminf(gym, gyp)), fminf(gzm, gzp));
+        const float be = needC ? fminf(sqrtf(bound) + kCertDelta, cover) : 0.0f;
+        const float be2 = fmaxf(be * be, bound);          // rows / cells are selected with this; never tighter than the bound itself
+        const float be2c = be * be * 0.99999f;            // what the certificate may rely on
+        const float rmax2 = wave_max_f32(needC ? be2 : 0.0f);
+
+        // ---- tile path: per group of 64 box rows, mark the rows some lane still needs, size them
+        // and stream them through the filter into the tile; gather only if the tile overflows.
+        // A box far larger than the lanes' own neighbourhoods (scattered points) is not worth staging, and neither is
+        // a tile for a handful of lanes.
+        const int tile_cap = kTilePts;
+        const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
+        const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
+        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * nC && (nC > kGatherLanes || (ablate & 128));
+        if (HOOK && !tile) prof.why = 1;
+        int nt = 0, ntf = 0;                              // tile fill from the front (near) and the back (far), wave-uniform
+        const float wcx = 0.5f * (mnx + mxx), wcy = 0.5f * (mny + mxy), wcz = 0.5f * (mnz + mxz);
+        const float whd = 0.5f * sqrtf(((mxx - mnx) * (mxx - mnx) + (mxy - mny) * (mxy - mny)) + (mxz - mnz) * (mxz - mnz));
+        const float near2 = (whd + 0.45f) * (whd + 0.45f);
+        for (int rg = 0; rg < R && tile; rg += 64) {
+            // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
+            unsigned long long want = 0ull;
+            if (needC) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int dyc = run_dy(k), dzc = run_dz(k);
+                    const int yy = cy + dyc, zz = cz + dzc;
+                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
+                    const int r = (zz - bz0) * nyb + (yy - by0) - rg;
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > be2) && r >= 0 && r < 64)
+                        want |= 1ull << r;
+                }
+            }
+            const uint32_t nlo = wave_or_u32((uint32_t)want), nhi = wave_or_u32((uint32_t)(want >> 32));
+            const bool mine = (((lane < 32) ? (nlo >> lane) : (nhi >> (lane - 32))) & 1u) != 0u;
+            int gs = 0, len = 0;                          // lane r: row rg + r of the box
+            if (mine) {                                   // whole rows: a compact wave's box is narrow in x
+                const int r = rg + lane;
+                const int zq = r / nyb;
+                const int gcell = ((bz0 + zq) * g.ny + by0 + (r - zq * nyb)) * g.nx;
+                gs = cell_start[gcell + bx0];
+                len = cell_start[gcell + bx1 + 1] - gs;
+            }
+            const int ptot = __builtin_amdgcn_readlane(wave_incl_scan_i32(len), 63);
+            if (HOOK) prof.raw += ptot;
+            if (ptot > kTileRaw) { tile = false; if (HOOK) prof.why = 2; break; }
+            // ---- stage through the filter: 16 lanes per row, 8 rows in flight per pass; a point
+            // enters the tile only if it lies inside the lanes' point box grown by the largest radius.
+            // Rows nobody marked, and marked rows that are empty, are squeezed out first (through LDS): every
+            // batch of 8 rows costs a dependent round trip to the map whatever it holds.
+            const int sub = lane >> 4, l16 = lane & 15;
+            const unsigned long long nzrows = __ballot(len > 0);
+            const int nr = __popcll(nzrows);
+            if (len > 0) lrows[__popcll(nzrows & ((1ull << lane) - 1ull))] = make_int2(gs, len);
+            wave_lds_sync();
+            for (int cb = 0; cb < nr && tile; cb += 8) {
+                const int ca = cb + sub, cc = cb + 4 + sub;
+                int gsa = 0, na = 0, gsc = 0, nn = 0;
+                if (ca < nr) { const int2 rw = lrows[ca]; gsa = rw.x; na = rw.y; }
+                if (cc < nr) { const int2 rw = lrows[cc]; gsc = rw.x; nn = rw.y; }
+                const int npass = wave_max_i32(max(na, nn));
+                for (int k0 = 0; k0 < npass; k0 += 16) {
+                    const int k = k0 + l16;
+                    v4f pa_v = { 0, 0, 0, 0 }, pc_v = { 0, 0, 0, 0 };
+                    const bool ha = k < na, hc = k < nn;
+                    if (ha) pa_v = map[gsa + k];
+                    if (hc) pc_v = map[gsc + k];
+                    pa_v.w = __int_as_float(gsa + k);     // the tile keeps the map POSITION as the key's low word
+                    pc_v.w = __int_as_float(gsc + k);
+                    const bool ia = ha && pa_v.x >= fx0 && pa_v.x <= fx1 && pa_v.y >= fy0 && pa_v.y <= fy1 && pa_v.z >= fz0 && pa_v.z <= fz1;
+                    const bool ic = hc && pc_v.x >= fx0 && pc_v.x <= fx1 && pc_v.y >= fy0 && pc_v.y <= fy1 && pc_v.z >= fz0 && pc_v.z <= fz1;
+                    // near the wave's centre -> front of the tile, the rest -> back: a full sweep then
+                    // meets every lane's likely neighbours first and its bound is tight for the remainder
+                    const float ax = pa_v.x - wcx, ay = pa_v.y - wcy, az = pa_v.z - wcz;
+                    const float bx = pc_v.x - wcx, by = pc_v.y - wcy, bz = pc_v.z - wcz;
+                    const bool na_ = (ax * ax + ay * ay) + az * az <= near2, nc_ = (bx * bx + by * by) + bz * bz <= near2;
+                    const unsigned long long man = __ballot(ia && na_), maf = __ballot(ia && !na_);
+                    const unsigned long long mcn = __ballot(ic && nc_), mcf = __ballot(ic && !nc_);
+                    const int an = __popcll(man), af = __popcll(maf), cn = __popcll(mcn), cf = __popcll(mcf);
+                    if (nt + ntf + an + af + cn + cf > tile_cap) { tile = false; if (HOOK) prof.why = 3; break; }
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (ia) lpts[na_ ? nt + __popcll(man & below) : tile_cap - 1 - (ntf + __popcll(maf & below))] = pa_v;
+                    if (ic) lpts[nc_ ? nt + an + __popcll(mcn & below) : tile_cap - 1 - (ntf + af + __popcll(mcf & below))] = pc_v;
+                    nt += an + cn; ntf += af + cf;
+                }
+            }
+        }
+
+        bool glanes = false;                              // lanes that take the gather path
+        if (tile) {
+            wave_lds_sync();
+            if (HOOK) { prof.mode = 1; prof.pts = nt + ntf; }
+            // ---- verify: count the tile points with d2 <= bound and find the nearest one beyond it (branch-free).
+            //  - complete tuple and exactly 5 inside: no OTHER point lies within the tuple's 5th distance (its 5 points
+            //    are in the tile: their rows were marked and they pass the filter), so the tuple stands; the nearest
+            //    point beyond the bound is the 6th neighbour: r6 for the next certificate;
+            //  - bound is the gate and fewer than 5 inside: the point is not gated, whatever its neighbours are.
+            bool todo = needC;                            // lanes that still need a sweep
+            float tb = bound;                             // radius (squared) of this lane's candidate list ...
+            int ccnt = 0;                                 // ... and the number of tile points inside it
+            {
+                // the stored tuple counts as a candidate answer only while all five of its points are inside the bound
+                const bool prior_ok = needC && best.key[4] != kKeyInf && __uint_as_float(key_hi(best.key[4])) <= bound;
+                // A wave of a split chunk holds 32, 16 or 8 points in its first lanes; when all of them search, the idle
+                // lanes join in: kq = 2, 4 or 8 lanes share a point, each counts every kq-th tile point, and the partial
+                // results are combined across the group.  (These short waves sit in dense parts of the map.)
+                // `cold`: some lane has no tuple (first launch of a scan).  Its bound is the gate, and a candidate list cut
+                // at the gate could be long; so the sweep counts against four radii at once (bound, /2, /4, /8) and each
+                // lane keeps the tightest one that still holds 5 points: tb, with ccnt points inside.
+                const bool cold = __ballot(needC && !prior_ok) != 0ull;
+                const bool packed = cmask == ((chunk.y >= 64) ? ~0ull : ((1ull << chunk.y) - 1ull));
+                const int kq = (cold || !packed) ? 1 : ((chunk.y > 32) ? 1 : ((chunk.y > 16) ? 2 : ((chunk.y > 8) ? 4 : 8)));
+                const int nslot = 64 / kq, part = lane / nslot;
+                float qx_ = sx, qy_ = sy, qz_ = sz, qb_ = bound;
+                if (kq > 1) {
+                    const int src = lane & (nslot - 1);
+                    qx_ = __shfl(sx, src, 64); qy_ = __shfl(sy, src, 64); qz_ = __shfl(sz, src, 64); qb_ = __shfl(bound, src, 64);
+                }
+                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                float m6 = INFINITY;                       // nearest tile point beyond the bound
+                if (cold) {
+                    const float t1 = bound * 0.5f, t2 = bound * 0.25f, t3 = bound * 0.125f;
+                    for (int seg = 0; seg < 2; seg++) {
+                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                        int j = jb;
+                        for (; j + 4 <= je; j += 4) {         // four LDS reads in flight
+                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                            float d0, d1, d2v, d3;
+                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                            c0 += ((d0 <= bound) ? 1 : 0) + ((d1 <= bound) ? 1 : 0) + ((d2v <= bound) ? 1 : 0) + ((d3 <= bound) ? 1 : 0);
+                            c1 += ((d0 <= t1) ? 1 : 0) + ((d1 <= t1) ? 1 : 0) + ((d2v <= t1) ? 1 : 0) + ((d3 <= t1) ? 1 : 0);
+                            c2 += ((d0 <= t2) ? 1 : 0) + ((d1 <= t2) ? 1 : 0) + ((d2v <= t2) ? 1 : 0) + ((d3 <= t2) ? 1 : 0);
+                            c3 += ((d0 <= t3) ? 1 : 0) + ((d1 <= t3) ? 1 : 0) + ((d2v <= t3) ? 1 : 0) + ((d3 <= t3) ? 1 : 0);
+                            m6 = fminf(fminf(m6, (d0 > bound) ? d0 : INFINITY), (d1 > bound) ? d1 : INFINITY);
+                            m6 = fminf(fminf(m6, (d2v > bound) ? d2v : INFINITY), (d3 > bound) ? d3 : INFINITY);
+                        }
+                        for (; j < je; j++) {
+                            float d; make_key(lpts[j], sx, sy, sz, d);
+                            c0 += (d <= bound) ? 1 : 0; c1 += (d <= t1) ? 1 : 0; c2 += (d <= t2) ? 1 : 0; c3 += (d <= t3) ? 1 : 0;
+                            m6 = fminf(m6, (d > bound) ? d : INFINITY);
+                        }
+                    }
+                    tb = (c3 >= 5) ? t3 : ((c2 >= 5) ? t2 : ((c1 >= 5) ? t1 : bound));
+                    ccnt = (c3 >= 5) ? c3 : ((c2 >= 5) ? c2 : ((c1 >= 5) ? c1 : c0));
+                    c1 = 0; c2 = 0; c3 = 0;               // c0 = points inside `bound`, as in the other branches
+                } else if (kq == 1) {                     // the common case, with compile-time LDS offsets
+                    float ma = INFINITY, mb = INFINITY;
+                    for (int seg = 0; seg < 2; seg++) {
+                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                        int j = jb;
+                        for (; j + 4 <= je; j += 4) {
+                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                            float d0, d1, d2v, d3;
+                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                            c0 += (d0 <= bound) ? 1 : 0; c1 += (d1 <= bound) ? 1 : 0;
+                            c2 += (d2v <= bound) ? 1 : 0; c3 += (d3 <= bound) ? 1 : 0;
+                            ma = fminf(fminf(ma, (d0 > bound) ? d0 : INFINITY), (d1 > bound) ? d1 : INFINITY);
+                            mb = fminf(fminf(mb, (d2v > bound) ? d2v : INFINITY), (d3 > bound) ? d3 : INFINITY);
+                        }
+                        for (; j < je; j++) {
+                            float d; make_key(lpts[j], sx, sy, sz, d);
+                            c0 += (d <= bound) ? 1 : 0;
+                            ma = fminf(ma, (d > bound) ? d : INFINITY);
+                        }
+                    }
+                    m6 = fminf(ma, mb);
+                } else {
+                    for (int seg = 0; seg < 2; seg++) {
+                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                        int j = jb + part;
+                        for (; j + 3 * kq < je; j += 4 * kq) {
+                            const v4f m0 = lpts[j], m1 = lpts[j + kq], m2 = lpts[j + 2 * kq], m3 = lpts[j + 3 * kq];
+                            float d0, d1, d2v, d3;
+                            make_key(m0, qx_, qy_, qz_, d0); make_key(m1, qx_, qy_, qz_, d1);
+                            make_key(m2, qx_, qy_, qz_, d2v); make_key(m3, qx_, qy_, qz_, d3);
+                            c0 += (d0 <= qb_) ? 1 : 0; c1 += (d1 <= qb_) ? 1 : 0;
+                            c2 += (d2v <= qb_) ? 1 : 0; c3 += (d3 <= qb_) ? 1 : 0;
+                            m6 = fminf(fminf(m6, (d0 > qb_) ? d0 : INFINITY), (d1 > qb_) ? d1 : INFINITY);
+                            m6 = fminf(fminf(m6, (d2v > qb_) ? d2v : INFINITY), (d3 > qb_) ? d3 : INFINITY);
+                        }
+                        for (; j < je; j += kq) {
+                            float d; make_key(lpts[j], qx_, qy_, qz_, d);
+                            c0 += (d <= qb_) ? 1 : 0;
+                            m6 = fminf(m6, (d > qb_) ? d : INFINITY);
+                        }
+                    }
+                }
+                int cnt = c0 + c1 + c2 + c3;
+                for (int m = nslot; m < 64; m <<= 1) { cnt += __shfl_xor(cnt, m, 64); m6 = fminf(m6, __shfl_xor(m6, m, 64)); }
+                if (!cold) ccnt = cnt;
+                if (prior_ok && cnt == 5) { todo = false; r6sq = fminf(m6, be2c); }
+                else if (needC && bound >= gatef && cnt < 5) { todo = false; far = true; r6sq = fminf(m6, be2c); }
+            }
+            // ---- lanes with a new, lost or missing neighbour.  The insertion network is a few dozen VALU and a wave
+            // pays it whenever ANY lane inserts, i.e. at nearly every tile point; so the lanes first write down
+            // the tile positions inside tb (a second branch-free sweep; exactly ccnt of them, >= 5 by
+            // construction, so the 5 nearest are among them) and then insert their k-th candidates together:
+            // ~10 wave-wide insertions instead of one per tile point.
+            if (__ballot(todo)) {
+                const bool use_list = todo && ccnt <= kCand;
+                if (__ballot(use_list)) {
+                    int cc = 0;
+                    if (use_list) {
+                        for (int seg = 0; seg < 2; seg++) {
+                            const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                            int j = jb;
+                            for (; j + 4 <= je; j += 4) {     // four LDS reads in flight
+                                const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                                float d0, d1, d2v, d3;
+                                make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                                make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                                if (d0 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
+                                if (d1 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 1); cc++; }
+                                if (d2v <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 2); cc++; }
+                                if (d3 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 3); cc++; }
+                            }
+                            for (; j < je; j++) {
+                                float d; make_key(lpts[j], sx, sy, sz, d);
+                                if (d <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
+                            }
+                        }
+                    }
+                    wave_lds_sync();
+                    const int cmax = wave_max_i32(cc);
+                    // candidate k+1 is fetched while candidate k is inserted; slots past cc hold stale positions (clamped, unused)
+                    v4f mk = lpts[min((int)lcand[lane], kTilePts - 1)];
+                    for (int k = 0; k < cmax; k++) {
+                        const v4f mn_ = lpts[min((int)lcand[min(k + 1, kCand - 1) * 64 + lane], kTilePts - 1)];
+                        if (k < cc) consider(best, bound, gatef, tieb, mk, sx, sy, sz);
+                        mk = mn_;
+                    }
+                    todo = todo && !use_list;
+                }
+            }
+            // ---- full sweep for whoever is left (a candidate list that would not fit): the tile, near segment first
+            if (__ballot(todo)) {
+                if (todo) {
+                    for (int seg = 0; seg < 2; seg++) {
+                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
+                        int j = jb;
+                        for (; j + 4 <= je; j += 4) {
+                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                            consider(best, bound, gatef, tieb, m0, sx, sy, sz);
+                            consider(best, bound, gatef, tieb, m1, sx, sy, sz);
+                            consider(best, bound, gatef, tieb, m2, sx, sy, sz);
+                            consider(best, bound, gatef, tieb, m3, sx, sy, sz);
+                        }
+                        for (; j < je; j++) consider(best, bound, gatef, tieb, lpts[j], sx, sy, sz);
+                    }
+                }
+            }
+        }
+        if (!tile) glanes = needC;
+        // ---- serve: the whole wave works for one searching lane at a time.  Lanes 0..8 size the lane's (<= 9) x-runs,
+        // the candidates (all map points of those cells) are read 64 at a time, their keys kept in the wave's LDS area,
+        // counted against the lane's bound like in the tile path; only when the tuple did change, six rounds of
+        // "smallest key above the last one" pick the new tuple and the 6th neighbour (r6 for the certificate).
+        // ~2 dependent round trips per served lane instead of one per run: a handful of lanes left over in a late
+        // launch costs a few microseconds, not the 20 of a lane walking its runs alone.
+        if (__ballot(glanes)) {
+            if (HOOK) prof.mode = tile ? 3 : 2;
+            uint64_t* lkeys = reinterpret_cast<uint64_t*>(lpts);
+            constexpr int kServeCap = kTilePts * 2;           // u64 keys that fit the tile area
+            unsigned long long pend = __ballot(glanes);
+            unsigned long long walk = 0ull;                    // lanes whose candidates did not fit: they walk their runs below
+            while (pend) {
+                const int L = (int)__builtin_ctzll(pend);
+                pend &= pend - 1ull;
+                const float qsx = lane_bcast(sx, L), qsy = lane_bcast(sy, L), qsz = lane_bcast(sz, L);
+                const float qb = lane_bcast(bound, L), qe2 = lane_bcast(be2, L);
+                const int qcx = __builtin_amdgcn_readlane(cx, L), qcy = __builtin_amdgcn_readlane(cy, L), qcz = __builtin_amdgcn_readlane(cz, L);
+                const float qy2m = lane_bcast(gy2m, L), qy2p = lane_bcast(gy2p, L), qz2m = lane_bcast(gz2m, L), qz2p = lane_bcast(gz2p, L);
+                const float qx2m = lane_bcast(gx2m, L), qx2p = lane_bcast(gx2p, L);
+                int rs = 0, rl = 0;
+                if (lane < 9) {
+                    const int dyc = run_dy(lane), dzc = run_dz(lane);
+                    const int yy = qcy + dyc, zz = qcz + dzc;
+                    const float lb = (dyc < 0 ? qy2m : (dyc > 0 ? qy2p : 0.0f)) + (dzc < 0 ? qz2m : (dzc > 0 ? qz2p : 0.0f));
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > qe2)) {
+                        const int xs = (qcx > 0 && lb + qx2m <= qe2) ? qcx - 1 : qcx;
+                        const int xe = (qcx < g.nx - 1 && lb + qx2p <= qe2) ? qcx + 1 : qcx;
+                        const int rb = (zz * g.ny + yy) * g.nx;
+                        rs = cell_start[rb + xs];
+                        rl = cell_start[rb + xe + 1] - rs;
+                    }
+                }
+                const int incl = wave_incl_scan_i32(rl);
+                const int P = __builtin_amdgcn_readlane(incl, 63);
+                if (P > kServeCap) { walk |= 1ull << L; continue; }
+                int rst[9], rpe[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) { rst[k] = __builtin_amdgcn_readlane(rs, k); rpe[k] = __builtin_amdgcn_readlane(incl, k); }
+                // phase 1: keys into LDS, count inside the bound, nearest beyond it
+                int cnt = 0;
+                float m6 = INFINITY;
+                for (int base = 0; base < P; base += 64) {
+                    const int t = base + lane;
+                    int off = rst[0];
+#pragma unroll
+                    for (int k = 1; k < 9; k++) off = (t >= rpe[k - 1]) ? (rst[k] - rpe[k - 1]) : off;
+                    if (t < P) {
+                        v4f m = map[t + off];
+                        m.w = __int_as_float(t + off);
+                        float d2;
+                        const uint64_t key = make_key(m, qsx, qsy, qsz, d2);
+                        lkeys[t] = key;
+                        cnt += (d2 <= qb) ? 1 : 0;
+                        m6 = fminf(m6, (d2 > qb) ? d2 : INFINITY);
+                    }
+                }
+                if (HOOK) prof.pts += P;
+                cnt = __builtin_amdgcn_readlane(wave_incl_scan_i32(cnt), 63);
+                m6 = wave_min_f32(m6);
+                const uint64_t k5 = __shfl(best.key[4], L, 64);                 // wave-uniform copy of the served lane's 5th key
+                const bool prior_ok = k5 != kKeyInf && __uint_as_float(key_hi(k5)) <= qb;
+                if (prior_ok && cnt == 5) {
+                    if (lane == L) r6sq = fminf(m6, be2c);
+                } else if (qb >= gatef && cnt < 5) {
+                    if (lane == L) { far = true; r6sq = fminf(m6, be2c); }
+                } else {
+                    // phase 2: the six smallest keys, one per round
+                    wave_lds_sync();
+                    uint64_t last = 0ull, found[6];
+#pragma unroll
+                    for (int r = 0; r < 6; r++) {
+                        uint64_t mine = kKeyInf | 0xffffffffull;                 // above every real key
+                        for (int t = lane; t < P; t += 64) {
+                            const uint64_t k = lkeys[t];
+                            const bool c = (r == 0 || k > last) && k < mine;
+                            mine = c ? k : mine;
+                        }
+                        // 64-bit minimum over the wave: distance word first, position word among its holders
+                        const uint32_t hmin = wave_min_u32(key_hi(mine));
+                        const uint32_t lmin = wave_min_u32(key_hi(mine) == hmin ? key_lo(mine) : 0xffffffffu);
+                        last = ((uint64_t)hmin << 32) | lmin;
+                        found[r] = last;
+                    }
+                    if (lane == L) {
+#pragma unroll
+                        for (int r = 0; r < 5; r++) {
+                            const bool have = key_hi(found[r]) < 0x7f800000u && __uint_as_float(key_hi(found[r])) <= qb;
+                            best.key[r] = have ? found[r] : kKeyInf;
+                        }
+                        const bool six = key_hi(found[5]) < 0x7f800000u;
+                        r6sq = best.key[4] != kKeyInf ? fminf(six ? __uint_as_float(key_hi(found[5])) : INFINITY, be2c) : 0.0f;
+                        if (six && key_hi(found[5]) == key_hi(found[4])) tieb = key_hi(found[4]);   // 5th and 6th at the same distance
+                        bound = fminf(__uint_as_float(key_hi(best.key[4])), gatef);
+                    }
+                }
+                wave_lds_sync();                                  // the next lane's keys go to the same LDS area
+            }
+            glanes = glanes && ((walk >> lane) & 1ull) != 0ull;
+        }
+        if (__ballot(glanes)) {
+            // ---- gather: run bounds of all 9 rows first (independent loads, kept in LDS), then the runs
+            int32_t (*lrun)[64] = reinterpret_cast<int32_t (*)[64]>(lpts);
+            if (glanes) {
+                int rs[9], re[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const int dyc = run_dy(k), dzc = run_dz(k);
+                    const int yy = cy + dyc, zz = cz + dzc;
+                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
+                    rs[k] = 0; re[k] = 0;
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > be2)) {
+                        const int xs = (x0 < cx && lb + gx2m <= be2) ? x0 : cx;     // left cell still reachable?
+                        const int xe = (x1 > cx && lb + gx2p <= be2) ? x1 : cx;     // right cell?
+                        const int rb = (zz * g.ny + yy) * g.nx;
+                        rs[k] = cell_start[rb + xs];
+                        re[k] = cell_start[rb + xe + 1];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) { lrun[2 * k][lane] = rs[k]; lrun[2 * k + 1][lane] = re[k]; }
+            }
+            wave_lds_sync();
+            if (glanes) {
+                // ---- verify first (same argument as in the tile path): count this lane's candidates with d2 <= bound
+                // and find the nearest one beyond, branch-free.  The first 4 points of run k+1 are in flight while run k
+                // is counted.  The key's low word is the position: set from the loop index.
+                bool full_pass = true;
+                {
+                    const bool prior_ok = best.key[4] != kKeyInf && __uint_as_float(key_hi(best.key[4])) <= bound;
+                    int cnt = 0;
+                    float m6 = INFINITY;
+                    int jn = lrun[0][lane], en = lrun[1][lane];
+                    v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
+                    if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+#pragma unroll 1
+                    for (int k = 0; k < 9; k++) {
+                        const int j0 = jn, e = en;
+                        const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
+                        if (k < 8) {
+                            jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
+                            if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+                        }
+                        if (j0 < e) {
+                            float d0, d1, d2v, d3;
+                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                            cnt += (d0 <= bound) ? 1 : 0;
+                            cnt += (j0 + 1 < e && d1 <= bound) ? 1 : 0;          // past the end the last point was re-read
+                            cnt += (j0 + 2 < e && d2v <= bound) ? 1 : 0;
+                            cnt += (j0 + 3 < e && d3 <= bound) ? 1 : 0;
+                            m6 = fminf(fminf(m6, (d0 > bound) ? d0 : INFINITY), (d1 > bound) ? d1 : INFINITY);
+                            m6 = fminf(fminf(m6, (d2v > bound) ? d2v : INFINITY), (d3 > bound) ? d3 : INFINITY);
+                            if (HOOK) prof.pts += e - j0;
+                            for (int j = j0 + 4; j < e; j += 4) {                  // long runs: 4 loads in flight
+                                const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
+                                make_key(q0, sx, sy, sz, d0); make_key(q1, sx, sy, sz, d1);
+                                make_key(q2, sx, sy, sz, d2v); make_key(q3, sx, sy, sz, d3);
+                                cnt += (d0 <= bound) ? 1 : 0;
+                                cnt += (j + 1 < e && d1 <= bound) ? 1 : 0;
+                                cnt += (j + 2 < e && d2v <= bound) ? 1 : 0;
+                                cnt += (j + 3 < e && d3 <= bound) ? 1 : 0;
+                                m6 = fminf(fminf(m6, (d0 > bound) ? d0 : INFINITY), (d1 > bound) ? d1 : INFINITY);
+                                m6 = fminf(fminf(m6, (d2v > bound) ? d2v : INFINITY), (d3 > bound) ? d3 : INFINITY);
+                            }
+                        }
+                    }
+                    if (prior_ok && cnt == 5) { full_pass = false; r6sq = fminf(m6, be2c); }
+                    else if (bound >= gatef && cnt < 5) { full_pass = false; far = true; r6sq = fminf(m6, be2c); }
+                }
+                // ---- full pass for the lanes that gained, lost or lack a neighbour (lines now L2-warm)
+                if (full_pass) {
+                    int jn = lrun[0][lane], en = lrun[1][lane];
+                    v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
+                    if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+#pragma unroll 1
+                    for (int k = 0; k < 9; k++) {
+                        const int j0 = jn, e = en;
+                        v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
+                        if (k < 8) {
+                            jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
+                            if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
+                        }
+                        const int dyc = run_dy(k), dzc = run_dz(k);
+                        const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
+                        if (j0 < e && !(lb > bound)) {                                 // bound may have tightened meanwhile
+                            m0.w = __int_as_float(j0); m1.w = __int_as_float(min(j0 + 1, e - 1));
+                            m2.w = __int_as_float(min(j0 + 2, e - 1)); m3.w = __int_as_float(min(j0 + 3, e - 1));
+                            consider(best, bound, gatef, tieb, m0, sx, sy, sz);
+                            consider(best, bound, gatef, tieb, m1, sx, sy, sz);
+                            consider(best, bound, gatef, tieb, m2, sx, sy, sz);
+                            consider(best, bound, gatef, tieb, m3, sx, sy, sz);
+                            for (int j = j0 + 4; j < e; j += 4) {                      // long runs: 4 loads in flight
+                                v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
+                                q0.w = __int_as_float(j); q1.w = __int_as_float(min(j + 1, e - 1));
+                                q2.w = __int_as_float(min(j + 2, e - 1)); q3.w = __int_as_float(min(j + 3, e - 1));
+                                consider(best, bound, gatef, tieb, q0, sx, sy, sz);
+                                consider(best, bound, gatef, tieb, q1, sx, sy, sz);
+                                consider(best, bound, gatef, tieb, q2, sx, sy, sz);
+                                consider(best, bound, gatef, tieb, q3, sx, sy, sz);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- a tie across the 5th/6th boundary: the exact walk decides who is fifth
+        const bool tied = needC && !far && best.key[4] != kKeyInf && tieb == key_hi(best.key[4]);
+        if (__ballot(tied)) {
+            if (tied) { exact_top5_of_cells(map, cell_start, g, cx, cy, cz, sx, sy, sz, gatef, best); r6sq = 0.0f; }
+        }
+    }
+
+    // ---- the outcome for every lane that re-measured or searched
+    const bool upd = passB || needC;
+    uint64_t fk[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) fk[k] = passB ? sk[k] : best.key[k];
+    const bool complete = upd && !far && key_hi(fk[4]) < 0x7f800000u;
+    bool changed = !had5;
+#pragma unroll
+    for (int k = 0; k < 5; k++) changed = changed || ((int)key_lo(fk[k]) != opos[k]);
+    // coordinates + original indices of the final tuple (L2-warm): unconditional so that nothing of the
+    // re-measuring above has to stay in registers across the search
+    v4f nb[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) nb[k] = map[complete ? (int)key_lo(fk[k]) : 0];
+    {   // equal distances inside the tuple: the reference order is (d2, ORIGINAL index)
+        bool tie_adj = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) tie_adj = tie_adj || (key_hi(fk[k]) == key_hi(fk[k + 1]));
+        tie_adj = tie_adj && complete;
+        if (__ballot(tie_adj)) {
+            if (tie_adj) {
+#pragma unroll
+                for (int pass = 0; pass < 4; pass++)
+#pragma unroll
+                    for (int k = 0; k < 4 - pass; k++) {
+                        const bool c = key_hi(fk[k]) == key_hi(fk[k + 1]) && __float_as_int(nb[k].w) > __float_as_int(nb[k + 1].w);
+                        const uint64_t tk = fk[k]; fk[k] = c ? fk[k + 1] : tk; fk[k + 1] = c ? tk : fk[k + 1];
+                        const v4f tn = nb[k]; nb[k] = c ? nb[k + 1] : tn; nb[k + 1] = c ? tn : nb[k + 1];
+                    }
+                changed = !had5;
+#pragma unroll
+                for (int k = 0; k < 5; k++) changed = changed || ((int)key_lo(fk[k]) != opos[k]);
+            }
+        }
+    }
+
+    if (upd) {
+        const float d2_5 = __uint_as_float(key_hi(fk[4]));
+        const bool gated = complete && ((double)d2_5 < cp->gate_sq);                  // :1097
+        // The LS plane and its inlier test depend only on the ordered neighbour tuple, not on the pose: a point
+        // that kept its tuple keeps its plane (and its verdict) bit for bit.
+        int pst = (!changed && !(ablate & 32)) ? (ost & 3) : 0;
+        if (gated && pst == 0) {
+            float qr[5][3];
+#pragma unroll
+            for (int j = 0; j < 5; j++) { qr[j][0] = nb[j].x; qr[j][1] = nb[j].y; qr[j][2] = nb[j].z; }   // :1099-1101
+            float X[3];
+            plane_fit_5x3(qr, X);                                                    // :1104
+            float pa = X[0], pb = X[1], pc = X[2], pd = 1.0f;
+            const float ps = sqrtf(pa * pa + pb * pb + pc * pc);                      // :1111
+            pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+            bool planeValid = true;
+#pragma unroll
+            for (int j = 0; j < 5; j++) {                                            // :1115-1122
+                const float r = pa * nb[j].x + pb * nb[j].y + pc * nb[j].z + pd;
+                if ((double)fabsf(r) > cp->plane_tol) planeValid = false;
+            }
+            const v4f pl = { planeValid ? pa : NAN, pb, pc, pd };                     // pa = NaN: contributes nothing
+            planep[i] = pl;
+            pst = planeValid ? 1 : 2;
+        } else if (!gated) {
+            const v4f pl = { NAN, 0.0f, 0.0f, 0.0f };
+            planep[i] = pl;
+            pst = 0;
+        }
+        // the certificate for the launches to come
+        float slack = 0.0f, r6 = 0.0f;
+        if (far) {
+            r6 = sqrtf(r6sq);
+            slack = r6 - cp->gate_r - 2.0f * kCertMargin;                             // stays "fewer than 5 inside the gate"
+        } else if (complete) {
+            float dk[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) dk[k] = sqrtf(__uint_as_float(key_hi(fk[k])));
+            r6 = passB ? (r6o - eps) : ((r6sq > 0.0f) ? sqrtf(r6sq) : dk[4]);
+            float gap = r6 - dk[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) gap = fminf(gap, dk[k + 1] - dk[k]);
+            slack = 0.5f * gap - kCertMargin;
+            slack = gated ? fminf(slack, cp->gate_r - dk[4] - 2.0f * kCertMargin) : 0.0f;
+        }
+        slack = (slack > 0.0f) ? slack : 0.0f;                                        // also NaN -> 0
+        const v4f cnew = { sx, sy, sz, slack };
+        certp[i] = cnew;
+        const v2i anew = { __float_as_int(r6), pst | (complete ? 4 : 0) };
+        auxp[i] = anew;
+        if (complete && changed) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) nposp[(size_t)k * nq + i] = (int)key_lo(fk[k]);
+        }
+        if (HOOK) {
+            const int o = G(cp->qperm)[i];
+            if (cp->dbg_idx5) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) G(cp->dbg_idx5)[5 * (size_t)o + j] = gated ? __float_as_int(nb[j].w) : -1;
+            }
+            if (cp->dbg_d2) {
+#pragma unroll
+                for (int j = 0; j < 5; j++) G(cp->dbg_d2)[5 * (size_t)o + j] = __uint_as_float(key_hi(fk[j]));
+            }
+        }
+    } else if (HOOK && valid && !fin) {
+        const int o = G(cp->qperm)[i];
+        if (cp->dbg_idx5) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) G(cp->dbg_idx5)[5 * (size_t)o + j] = -1;
+        }
+        if (cp->dbg_d2) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) G(cp->dbg_d2)[5 * (size_t)o + j] = INFINITY;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2: residual, weight, Jacobian row and the 28 products of one wave-table entry (:1125-1139, :1216-1239)
+// ------------------------------------------------------------------------------------------
+template <bool HOOK>
+__device__ __forceinline__ void linearise_point(const DevCtx* __restrict__ cp, const float (&T)[12], const float (&sc6)[6],
+                                                int i, float px, float py, float pz, const v4f pl, double (&acc)[kAcc])
+{
+    const float sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
+    const float sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
+    const float sz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
+    const bool fin = (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
+    bool keep = false;
+    float cf[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    if (fin && pl.x == pl.x) {                                                        // gated, plane passed the inlier test
+        const float pa = pl.x, pb = pl.y, pc = pl.z, pd = pl.w;
+        const float pd2 = pa * sx + pb * sy + pc * sz + pd;                           // :1125
+        const float rr = sqrtf(sqrtf(px * px + py * py + pz * pz));
+        const float sw = (float)(1.0 - cp->weight_scale * (double)fabsf(pd2) / (double)rr);   // :1127
+        if ((double)sw > cp->weight_min) {                                            // :1135
+            cf[0] = sw * pa; cf[1] = sw * pb; cf[2] = sw * pc; cf[3] = sw * pd2;      // :1130-1133
+            keep = true;
+        }
+    }
+    if (keep) {
+        float row[6], rhs;
+        jacobian_row(sc6, px, py, pz, cf, row, rhs);
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int b = a; b < 6; b++) acc[k++] += (double)row[a] * (double)row[b];
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[21 + a] += (double)row[a] * (double)rhs;
+        acc[27] += 1.0;
+    }
+    if (HOOK) {
+        const int o = G(cp->qperm)[i];
+        if (cp->dbg_flag) G(cp->dbg_flag)[o] = keep ? 1 : 0;
+        if (cp->dbg_coeff) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) G(cp->dbg_coeff)[4 * (size_t)o + j] = cf[j];
+        }
+    }
+}
+
+template <bool HOOK>
+__device__ __forceinline__ void linearise_chunk(const DevCtx* __restrict__ cp, const float (&T)[12], const float (&sc6)[6],
+                                                int2 chunk, int lane, double (&acc)[kAcc])
+{
+    const int i = chunk.x + lane;
+    if (!(lane < chunk.y && i < cp->n_q)) return;
+    const float px = G(cp->qx)[i], py = G(cp->qy)[i], pz = G(cp->qz)[i];              // pointOri (:1085)
+    const v4f pl = G((const v4f*)cp->plane_cache)[i];
+    linearise_point<HOOK>(cp, T, sc6, i, px, py, pz, pl, acc);
+}
+
+template <bool HOOK>
+__global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int launch, int solve_prev)
+{
+    constexpr int NW = kBlock / 64;
+    // The loop state block never moves, so it comes as a kernel argument: `done` and the wave count arrive
+    // with the first round trip, in parallel with the DevCtx block, instead of behind a pointer chase.
+    const auto st = G(state);
+    const int done = st->done, n_waves = st->n_waves;
+    if (!HOOK && done) return;
+    unsigned long long tk_start = 0, clk1 = 0, clk2 = 0;
+    unsigned long long lm_stamps[7] = { 0, 0, 0, 0, 0, 0, 0 };   // diagnostics of the fused LM close
+    if (HOOK) tk_start = wall_clock64();
+
+    __shared__ v4f     s_pts[NW][kTilePts];          // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
+    static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
+    __shared__ double  red[NW][32];
+    __shared__ uint16_t s_cand[NW][kCand * 64];     // per wave: tile positions of each lane's candidates, [k][lane]
+    __shared__ int2    s_rows[NW][64];              // per wave: the non-empty box rows of the current row group
+    __shared__ float   s_lm_out[8];                  // pose + loop-ended flag published by lm_close_iteration
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Wave w of workgroup b starts at entry w*nb_act + b of the wave table and advances by the number of waves in
+    // the grid: neighbouring entries (similar cost: the sort runs from the dense near field to the sparse far
+    // field) land on different CUs, which evens out both the work and the L2-miss queues.
+    const int nb_act = min((n_waves + NW - 1) / NW, (int)gridDim.x);       // workgroups the wave table needs
+    if ((int)blockIdx.x >= nb_act) return;                                  // the rest of the (fixed, graph-captured) grid idles
+    const int e0 = wave * nb_act + (int)blockIdx.x, estride = nb_act * NW;
+    const auto tb = G((const int2*)cp->wave_table);
+    const int nq = cp->n_q;
+    const GridDesc g = cp->g;
+    const auto map = G((const v4f*)cp->map_sorted);
+    const auto cell_start = G(cp->cell_start);
+    const int ablate = cp->ablate;
+    const float gatef = cp->gate_f;
+
+    // everything of the first entry that does not depend on the pose is requested first: it is in flight while the
+    // previous iteration is closed below
+    int2 chunk = make_int2(0, 0);
+    if (e0 < n_waves) { chunk.x = tb[e0].x; chunk.y = tb[e0].y; }
+    float px = 0.0f, py = 0.0f, pz = 0.0f;
+    v4f cert = { 0, 0, 0, 0 }, plane0 = { NAN, 0, 0, 0 };
+    const bool valid0 = lane < chunk.y && chunk.x + lane < nq;
+    if (valid0) {
+        const int i = chunk.x + lane;
+        px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
+        cert = G((const v4f*)cp->cert)[i];
+        plane0 = G((const v4f*)cp->plane_cache)[i];        // good as it is if the whole entry turns out to be certified
+    }
+
+    // transPointAssociateToMap (:1069-1072) and the LM trig (:1170-1175). Launch 0 of a scan gets them
+    // from the host (libm); later launches rebuild them from the pose: lanes 0..2 take one angle each
+    // (glibc's sinf / cosf arithmetic, see glibc_sincosf).  With solve_prev the pose is first advanced by closing
+    // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.
+    float T[12], sc6[6];
+    if (!solve_prev && st->T_valid) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = st->T[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sc6[k] = st->sc[k];
+    } else {
+        float pose[6];
+        if (solve_prev) {
+            static_assert(sizeof(LmShared) <= sizeof(v4f) * kTilePts * NW, "LM scratch must fit the tile area");
+            LmShared& sh = *reinterpret_cast<LmShared*>(&s_pts[0][0]);
+            const int degen0 = st->isDegenerate;
+            float pose0[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) pose0[k] = st->pose2[(launch - 1) & 1][k];
+            if (HOOK) lm_stamps[5] = wall_clock64();
+            const bool ended = lm_close_iteration<kBlock, false>(cp, st, nb_act, launch - 1, blockIdx.x == 0, false, pose0, degen0,
+                                                                 sh, s_lm_out, pose, HOOK ? lm_stamps : nullptr);
+            if (ended) return;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) pose[k] = st->pose2[launch & 1][k];
+        }
+        const float ang = (lane == 0) ? pose[2] : ((lane == 1) ? pose[1] : pose[0]);   // lane 0: yaw, 1: pitch, 2+: roll
+        float snf, csf;
+        glibc_sincosf_both(ang, snf, csf);                                         // what the host's libm would return
+        const float B = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 0)), A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 0));
+        const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 1)), C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 1));
+        const float F = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 2)), E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 2));
+        const float DE = D * E, DF = D * F;
+        T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = pose[3];
+        T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = pose[4];
+        T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = pose[5];
+        sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
+    }
+    if (HOOK) lm_stamps[6] = wall_clock64();
+
+    WaveProf prof;
+    double acc[kAcc];
+#pragma unroll
+    for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+    const bool single = e0 + estride >= n_waves;            // one entry for this wave (every scan up to 262 144 points): its point stays in registers
+    if (single) {
+        if (e0 < n_waves) {
+            // the certificate test of associate_chunk, up front: a fully certified entry goes straight to its residuals
+            const float sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
+            const float sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
+            const float sz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
+            const bool fin = valid0 && (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
+            const float ex = sx - cert.x, ey = sy - cert.y, ez = sz - cert.z;
+            const float eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
+            const bool need = fin && !(!(ablate & 1) && (eps < cert.w));
+            if (HOOK || __ballot(need)) {
+                associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
+                                      px, py, pz, cert, prof);
+                if (valid0) plane0 = G((const v4f*)cp->plane_cache)[chunk.x + lane];
+            }
+            if (HOOK) clk1 = wall_clock64();
+            if (valid0) linearise_point<HOOK>(cp, T, sc6, chunk.x + lane, px, py, pz, plane0, acc);
+        }
+    } else {
+    // ---- pass 1: associate
+    for (int e = e0; e < n_waves; e += estride) {
+        if (e != e0) {
+            chunk = make_int2(tb[e].x, tb[e].y);
+            px = 0.0f; py = 0.0f; pz = 0.0f; cert = v4f{ 0, 0, 0, 0 };
+            if (lane < chunk.y && chunk.x + lane < nq) {
+                const int i = chunk.x + lane;
+                px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];
+                cert = G((const v4f*)cp->cert)[i];
+            }
+        }
+        associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
+                              px, py, pz, cert, prof);
+    }
+    if (HOOK) clk1 = wall_clock64();
+
+    // ---- pass 2: linearise
+    for (int e = e0; e < n_waves; e += estride)
+        linearise_chunk<HOOK>(cp, T, sc6, make_int2(tb[e].x, tb[e].y), lane, acc);
+    }
+    if (HOOK) clk2 = wall_clock64();
+
+    // ---- wave reduction by recursive halving: at mask m a lane keeps one half of its sums and
+    // hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
+    // five steps lane l holds, in a[0], sum number l>>1 over its half-wave pair group, and one
+    // full exchange with lane^1 completes it.  Fixed order: bitwise reproducible.
+    const auto partial_row = G(cp->partials) + ((size_t)(launch & 1) * (size_t)cp->nblocks + blockIdx.x) * kAcc;   // slot launch & 1
+    double a[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) a[k] = (k < kAcc) ? acc[k] : 0.0;
+#pragma unroll
+    for (int h = 16, m = 32; h >= 1; h >>= 1, m >>= 1) {
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int j = 0; j < h; j++) {
+            const double keepv = up ? a[j + h] : a[j];
+            const double sendv = up ? a[j] : a[j + h];
+            a[j] = keepv + __shfl_xor(sendv, m, 64);
+        }
+    }
+    a[0] += __shfl_xor(a[0], 1, 64);
+    if ((lane & 1) == 0) red[wave][lane >> 1] = a[0];
+    if (HOOK && cp->dbg_clk && lane == 0) {
+        const auto d = G(cp->dbg_clk) + kProfWords * ((size_t)blockIdx.x * NW + wave);
+        d[0] = tk_start; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
+        d[4] = (unsigned long long)prof.mode; d[5] = (unsigned long long)prof.rows; d[6] = (unsigned long long)prof.pts; d[7] = (unsigned long long)prof.raw;
+        d[8] = (unsigned long long)prof.n_a; d[9] = (unsigned long long)prof.n_b; d[10] = (unsigned long long)chunk.y; d[11] = (unsigned long long)prof.n_c;
+        d[12] = 0; d[13] = (unsigned long long)prof.why; d[14] = 0; d[15] = 0;
+        // fused LM close (solve_prev launches): entry, partial sums reduced, normal equations, QR, update, barrier, T built
+        d[16] = lm_stamps[5]; d[17] = lm_stamps[0]; d[18] = lm_stamps[1]; d[19] = lm_stamps[2]; d[20] = lm_stamps[3]; d[21] = lm_stamps[4]; d[22] = lm_stamps[6]; d[23] = 0;
+    }
+    __syncthreads();
+    if (tid < kAcc) {
+        double s = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < NW; w++) s += red[w][tid];
+        partial_row[tid] = s;
+    }
+}
+

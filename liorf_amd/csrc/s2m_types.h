@@ -13,6 +13,7 @@ constexpr int kFinThreads = 1024;      // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
 constexpr int kProfWords = 24;         // uint64 words per wave written by the diagnostics variant of k_register
 constexpr int kBlocksQuantum = 8;      // graph cache key granularity (workgroups)
+constexpr int kMaxBlocks = 512;        // largest k_register grid: two 8-wave workgroups on each of the 256 CUs, all co-resident
 
 // Uniform search grid over the map: cell edge E >= sqrt(gate_sq)*(1+2^-10), so the 3x3x3
 // neighbourhood of a query's cell holds every map point with fp32 d2 < gate_sq.
@@ -51,12 +52,15 @@ struct DevCtx {
     const int32_t* cell_start;    // [ncells+1]
     const float* qx; const float* qy; const float* qz;   // [n_q] lidar-frame scan, SoA, locality-sorted
     const int32_t* qperm;         // [n_q] sorted position -> original scan index
-    float4*  prevp;               // [5][n_q] previous launch's neighbours per sorted scan point: x,y,z, map index
-    int32_t* prior_valid;         // [n_q] 1 if prevp holds 5 neighbours of the current map for this point
-    float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to prev5's tuple
-    int32_t* plane_state;         // [n_q] 0 none, 1 plane passed the inlier test, 2 plane failed it
-    int32_t n_q, n_m, nblocks;
-    const int2* wave_table;       // [nblocks*4] {first sorted point, count <= 64} per wave
+    // what a scan point remembers from launch to launch (see s2m_register.hpp); all reset by s2m_set_scan / s2m_set_map
+    int32_t* npos;                // [5][n_q] its 5 neighbours, ascending (d2, map index), as positions in map_sorted
+    float4*  cert;                // [n_q] {q_ref x,y,z: where the point stood when the tuple was established, slack: how far it may move}
+    int2*    aux;                 // [n_q] {r6 (float bits): no other map point was nearer than this at q_ref, state: bits 0-1 plane 0 none /
+                                  //        1 passed the inlier test / 2 failed it, bit 2 the tuple is complete}
+    float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to the tuple; pa = NaN: this point contributes nothing
+    int32_t n_q, n_m, nblocks;    // nblocks: workgroups of a k_register launch (<= kMaxBlocks; waves loop over the wave table)
+    int32_t table_cap;            // capacity of wave_table in entries
+    const int2* wave_table;       // [table_cap] {first sorted point, count <= 64} per wave-table entry
     const int32_t* n_waves;       // entries of wave_table in use
     // the same table for the kernels that rebuild it before launch 0 (k_wave_density, k_chunk_table_density)
     int2*    wave_table_rw; int32_t* n_waves_rw;
@@ -69,10 +73,11 @@ struct DevCtx {
     s2m_iter_trace* trace;        // [kMaxIter]
     // parameters
     float  gate_f;                // smallest fp32 >= gate_sq: nothing at or beyond it is observable
+    float  gate_r;                // sqrtf(gate_sq) rounded down: the gate as a distance
     double gate_sq, plane_tol, weight_scale, weight_min, conv_deg, conv_cm;
     float  eig_thresh;
     int32_t min_corr, max_iter, early_exit;
-    int32_t ablate;               // diagnostics only (env S2M_ABLATE): 1 skip search, 2 skip plane/Jacobian, 4 skip reduction, 8 skip staging, 16 ignore the prior, 32 ignore the plane cache, 64 gather path only
+    int32_t ablate;               // diagnostics and tests (env S2M_ABLATE): 1 no certificates (tier A off), 2 no re-measuring (tier B off), 16 ignore the stored tuple in the search, 32 ignore the plane cache, 64 gather path only, 128 tile path whatever the number of lanes
     // observation outputs of the hook variant (original scan order), may be null
     int32_t* dbg_idx5; float* dbg_d2; uint8_t* dbg_flag; float* dbg_coeff;
     unsigned long long* dbg_clk;  // [nwaves][kProfWords] per-wave wall-clock stamps + tile stats (diagnostics)

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device",
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
-    "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile",
+    "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile", "s2m_debug_time_steady",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
     "s2m_transform_cloud",
     "s2m_icp_default_params", "s2m_icp_align", "s2m_debug_device_trig",
@@ -136,6 +136,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_time_iteration_kernel.argtypes = [vp, fp, C.c_int, fp]
     L.s2m_time_iterations.argtypes = [vp, fp, C.c_int, fp, C.c_int]
     L.s2m_debug_wave_profile.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint64), C.c_size_t]
+    L.s2m_debug_time_steady.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.s2m_make_scancontext.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     szp = C.POINTER(C.c_size_t)
     for n in ("s2m_voxel_downsample", "s2m_voxel_downsample_device"):
@@ -412,6 +413,13 @@ class MapOptimizationS2M:
         out = np.zeros(64, np.float32)
         self._check(self.lib.s2m_time_iterations(self.h, _fp(p), reps, _fp(out), 64), "s2m_time_iterations")
         return out[:self.params.max_iter]
+
+    def time_steady(self, pose, reps: int = 200, solve_prev: bool = True) -> float:
+        """Diagnostics: microseconds per replayed steady-state launch (s2m_debug_time_steady)."""
+        p = np.ascontiguousarray(pose, np.float32)
+        us = C.c_float(0)
+        self._check(self.lib.s2m_debug_time_steady(self.h, _fp(p), reps, 1 if solve_prev else 0, C.byref(us)), "s2m_debug_time_steady")
+        return us.value
 
     def wave_profile(self, pose, launches: int = 3) -> np.ndarray:
         """Diagnostics: (n_waves, 24) uint64 per-wave stamps/stats of one k_register pass (include/liorf_s2m.h);
