@@ -47,7 +47,7 @@ struct s2m_context {
     // map side
     DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
     // scan side
-    DevBuf raw_scan, qx, qy, qz, qperm, npos, cert, aux, plane_cache, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
+    DevBuf raw_scan, qx, qy, qz, qperm, npos, nbr, cert, aux, plane_cache, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
     // voxel-grid stages that feed the path (section 8(f) F1/F2): staging for host clouds, transformed key frames, filtered clouds
@@ -231,7 +231,7 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
 
     if (h->have_scan && h->n_q > 0 && h->cert.p) {           // tuples and certificates of the old map are meaningless now
         S2M_HIP(h, hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream));
-        S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int2) * h->n_q, h->stream));
+        S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int4) * h->n_q, h->stream));
     }
     h->n_m = n;                                       // committed only now: a failure above leaves the old index in place
     h->hctx.n_m = (int32_t)n;
@@ -289,7 +289,8 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     if ((rc = ensure(h, h->npos, sizeof(int32_t) * 5 * n))) return rc;
     if ((rc = ensure(h, h->plane_cache, sizeof(float4) * n))) return rc;
     if ((rc = ensure(h, h->cert, sizeof(float4) * n))) return rc;           // cert and aux are reset by k_scatter_scan
-    if ((rc = ensure(h, h->aux, sizeof(int2) * n))) return rc;
+    if ((rc = ensure(h, h->aux, sizeof(int4) * n))) return rc;
+    if ((rc = ensure(h, h->nbr, sizeof(int32_t) * kNbrCap * n))) return rc;
     if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
     if ((rc = ensure(h, h->q_rank_of, sizeof(int32_t) * n))) return rc;
@@ -304,7 +305,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
                        (const int32_t*)h->q_cell_of.as<int32_t>(), (const int32_t*)h->q_rank_of.as<int32_t>(),
                        (const int32_t*)h->q_cell_start.as<int32_t>(),
                        h->qx.as<float>(), h->qy.as<float>(), h->qz.as<float>(), h->qperm.as<int32_t>(),
-                       h->cert.as<float4>(), h->aux.as<int2>());
+                       h->cert.as<float4>(), h->aux.as<int4>());
     S2M_HIP(h, hipGetLastError());
 
     h->hctx.qx = h->qx.as<float>(); h->hctx.qy = h->qy.as<float>(); h->hctx.qz = h->qz.as<float>();
@@ -335,7 +336,8 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     }
     h->hctx.npos = h->npos.as<int32_t>();
     h->hctx.cert = h->cert.as<float4>();
-    h->hctx.aux = h->aux.as<int2>();
+    h->hctx.aux = h->aux.as<int4>();
+    h->hctx.nbr = h->nbr.as<int32_t>();
     h->hctx.plane_cache = h->plane_cache.as<float4>();
     h->ctx_dirty = true;
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
@@ -633,7 +635,7 @@ int s2m_destroy(s2m_handle h)
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
-                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->npos, &h->cert, &h->aux, &h->plane_cache, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->npos, &h->nbr, &h->cert, &h->aux, &h->plane_cache, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out,
                        &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds,
@@ -935,7 +937,7 @@ static int time_iterations_impl(s2m_handle h, const float pose[6], int reps, flo
     for (int rep = 0; rep < reps; rep++) {
         // a new scan starts without a prior or cached planes (what s2m_set_scan leaves behind)
         S2M_HIP(h, hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream));
-        S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int2) * h->n_q, h->stream));
+        S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int4) * h->n_q, h->stream));
         if ((rc = push_state(h, pose))) return rc;
         enqueue_loop(h, h->hctx.nblocks, dc, h->iter_events.data());     // the real loop, launched one by one between event pairs
         h->hctx.density_pending = 0;

@@ -417,7 +417,7 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
                                const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
                                const int32_t* __restrict__ cell_start,
                                float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz,
-                               int32_t* __restrict__ qperm, float4* __restrict__ cert, int2* __restrict__ aux)
+                               int32_t* __restrict__ qperm, float4* __restrict__ cert, int4* __restrict__ aux)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -426,7 +426,7 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
     if ((unsigned)pos >= (unsigned)n) return;            // cannot happen while the histogram is consistent
     qx[pos] = p[0]; qy[pos] = p[1]; qz[pos] = p[2]; qperm[pos] = i;
     cert[pos] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // a new scan: no certificate (slack 0), no neighbour tuple, no plane
-    aux[pos] = make_int2(0, 0);
+    aux[pos] = make_int4(0, 0, 0, 0);
 }
 
 // Work-proportional wave assignment.  The sorted scan is cut into chunks of 64 points; a chunk

@@ -55,9 +55,14 @@
 // (included inside namespace s2m by s2m_kernels.hpp)
 
 constexpr float kCertMargin = 2e-6f;   // metres; see tier A above
-constexpr float kCertDelta  = 0.04f;   // metres the search looks beyond the 5th neighbour for the 6th
-constexpr int   kGatherLanes = 8;      // up to this many searching lanes are served one by one instead of staging a tile
-typedef int v2i __attribute__((ext_vector_type(2)));
+constexpr float kNbrReach   = 0.15f;   // metres beyond the 5th neighbour that a search tries to cover with the neighbourhood ...
+constexpr float kNbrReachCold = 0.10f; // ... and beyond the gate when it has no tuple to start from (first launch of a scan)
+constexpr int   kWalkLanes = 16;       // a wave whose tile overflowed serves up to this many lanes one by one; beyond, every lane walks its own cells
+constexpr int   kNbr = kNbrCap;        // neighbourhood capacity (map positions per scan point)
+constexpr int   kLevels = 6;           // radii a search counts against at once
+constexpr int   kServeLanes = 8;       // up to this many searching lanes are served one by one instead of staging a tile
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef float v3f __attribute__((ext_vector_type(3)));
 
 __device__ __forceinline__ uint32_t key_hi(uint64_t k) { return (uint32_t)(k >> 32); }
 __device__ __forceinline__ uint32_t key_lo(uint64_t k) { return (uint32_t)k; }
@@ -67,16 +72,20 @@ __device__ __forceinline__ void cas_u64(uint64_t& a, uint64_t& b)
     const uint64_t t = a;
     a = c ? b : a; b = c ? t : b;
 }
-// 5 keys, ascending: the 9-comparator network
-__device__ __forceinline__ void sort5_u64(uint64_t (&k)[5])
+
+// the 6 smallest keys seen, ascending: key = (fp32 d2 bits << 32) | position in map_sorted
+struct Top6k { uint64_t key[6]; };
+// returns the key that stays outside: the smallest of those over all insertions is the 7th nearest
+__device__ __forceinline__ uint64_t top6k_insert(Top6k& t, uint64_t key)
 {
-    cas_u64(k[0], k[1]); cas_u64(k[3], k[4]); cas_u64(k[2], k[4]); cas_u64(k[2], k[3]); cas_u64(k[1], k[4]);
-    cas_u64(k[0], k[3]); cas_u64(k[0], k[2]); cas_u64(k[1], k[3]); cas_u64(k[1], k[2]);
+    cas_u64(t.key[5], key);            // key > t.key[5]: nothing changes below
+#pragma unroll
+    for (int j = 5; j > 0; --j) cas_u64(t.key[j - 1], t.key[j]);
+    return key;
 }
 
-// exact top-5 of the search: key = (fp32 d2 bits << 32) | position in map_sorted, ascending
+// exact top-5 of the fallback sweep (a neighbourhood that would not fit): same keys
 struct Top5k { uint64_t key[5]; };
-
 __device__ __forceinline__ void top5k_insert(Top5k& t, uint64_t key)
 {
     t.key[4] = key;
@@ -93,15 +102,14 @@ __device__ __forceinline__ uint64_t make_key(const v4f m, float sx, float sy, fl
 }
 
 // bound = min(d2 of the current 5th best, gate): nothing at or beyond the gate is observable.
-// tieb remembers the d2 bits of a point that was met at exactly the 5th best's distance: if that is still the
-// 5th distance at the end, (d2, position) and (d2, original index) may disagree about who is fifth.
+// tieb remembers the d2 bits of a point that was met at exactly the 5th best's distance (or pushed out of the set at the
+// new 5th distance): if that is still the 5th distance at the end, (d2, position) and (d2, original index) may disagree
+// about who is fifth.
 __device__ __forceinline__ void consider(Top5k& best, float& bound, float gatef, uint32_t& tieb, const v4f m, float sx, float sy, float sz)
 {
     float d2;
     const uint64_t key = make_key(m, sx, sy, sz, d2);
     const uint32_t pos = key_lo(key), d2b = key_hi(key);
-    // one straight-line predicate, one branch.  A map point already in the set (the stored tuple's points are met
-    // again; the gather path re-reads the last point of a run) has the same position.
     const bool fresh = (pos != key_lo(best.key[0])) & (pos != key_lo(best.key[1])) & (pos != key_lo(best.key[2])) & (pos != key_lo(best.key[3]));
     const bool inb = d2 <= bound;
     const bool tie = inb & fresh & (d2b == key_hi(best.key[4])) & (pos != key_lo(best.key[4]));
@@ -114,9 +122,9 @@ __device__ __forceinline__ void consider(Top5k& best, float& bound, float gatef,
     }
 }
 
-// The exact walk that settles a tie across the 5th/6th boundary (rare: two map points at bit-identical distance):
-// the lane's 3x3x3 cells, keys (d2, ORIGINAL index), positions carried along.  Result as (d2 | position) keys in the
-// reference order.
+// The exact walk that settles a tie across the 5th/6th boundary in the fallback sweep (rare: two map points at
+// bit-identical distance): the lane's 3x3x3 cells, keys (d2, ORIGINAL index), positions carried along.  Result as
+// (d2 | position) keys in the reference order.
 __device__ __forceinline__ void exact_top5_of_cells(gptr<const v4f> map, gptr<const int32_t> cell_start, const GridDesc& g,
                                                     int cx, int cy, int cz, float sx, float sy, float sz, float gatef, Top5k& out)
 {
@@ -153,7 +161,7 @@ __device__ __forceinline__ void exact_top5_of_cells(gptr<const v4f> map, gptr<co
 
 // per-wave diagnostics of the hook variant
 struct WaveProf {
-    int mode = 0;              // search path taken by the last entry that searched: 1 tile, 2 gather, 3 tile then gather
+    int mode = 0;              // search path taken by the last entry that searched: 1 tile, 2 served, 3 tile overflow then served
     int n_a = 0, n_b = 0, n_c = 0;   // lanes settled by certificate / by re-measuring / by searching (summed over the wave's entries)
     int rows = 0, pts = 0, raw = 0, why = 0;
 };
@@ -187,79 +195,160 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     if (HOOK) prof.n_a += __popcll(__ballot(passA));
     if (!HOOK && !__ballot(need)) return;                                // the whole entry is certified
 
-    // ---- tier B: re-measure the stored tuple
-    const auto auxp = G((v2i*)cp->aux);
+    const auto auxp = G((v4i*)cp->aux);
     const auto nposp = G(cp->npos);
+    const auto nbrp = G(cp->nbr);
     const auto certp = G((v4f*)cp->cert);
     const auto planep = G((v4f*)cp->plane_cache);
+    const float gate_r = cp->gate_r;
+
+    // ---- what the point remembers: its tuple (for change detection), the radius its neighbourhood covers
     const bool lookB = HOOK ? fin : need;
-    int ost = 0;
-    float r6o = 0.0f;
+    int ost = 0, nb_n = 0;
+    float r_out = 0.0f, r7o = 0.0f;                      // r7o: every map point other than the first six members was at least this far from q_ref
     int opos[5] = { 0, 0, 0, 0, 0 };
     if (lookB) {
-        const v2i a = auxp[i];
-        r6o = __int_as_float(a.x); ost = a.y;
+        const v4i a = auxp[i];
+        r_out = __int_as_float(a.x); ost = a.y; nb_n = min(max(a.z, 0), kNbr); r7o = __int_as_float(a.w);
 #pragma unroll
         for (int j = 0; j < 5; j++) opos[j] = nposp[(size_t)j * nq + i];
     }
     const bool had5 = lookB && (ost & 4) != 0;
-    uint64_t sk[5];                                                      // the stored tuple at this pose: (d2 | position), re-sorted
-    {
-        v4f nb[5];
-#pragma unroll
-        for (int j = 0; j < 5; j++) nb[j] = map[had5 ? opos[j] : 0];
+    bool nbr_ok = lookB && (ost & 8) != 0;                // the stored neighbourhood holds every map point within r_out of q_ref (possibly none)
+    if (HOOK && valid && passA) {
+        // certified lanes report the stored tuple in the STORED order with the distances measured now: a wrong
+        // certificate shows up in the parity tests as a mis-ordered or wrong neighbour list
+        const int o = G(cp->qperm)[i];
+        const bool gatedA = (ost & 3) != 0;
 #pragma unroll
         for (int j = 0; j < 5; j++) {
+            const v4f m = map[had5 ? opos[j] : 0];
             float d2;
-            make_key(nb[j], sx, sy, sz, d2);
-            sk[j] = had5 ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)opos[j]) : kKeyInf;
-        }
-        if (HOOK && valid && passA) {
-            // certified lanes report the stored tuple in the STORED order with the distances measured now: a wrong
-            // certificate shows up in the parity tests as a mis-ordered or wrong neighbour list
-            const int o = G(cp->qperm)[i];
-            const bool gatedA = (ost & 3) != 0;
-            if (cp->dbg_idx5) {
-#pragma unroll
-                for (int j = 0; j < 5; j++) G(cp->dbg_idx5)[5 * (size_t)o + j] = gatedA ? __float_as_int(nb[j].w) : -1;
-            }
-            if (cp->dbg_d2) {
-#pragma unroll
-                for (int j = 0; j < 5; j++) G(cp->dbg_d2)[5 * (size_t)o + j] = gatedA ? __uint_as_float(key_hi(sk[j])) : INFINITY;
-            }
+            make_key(m, sx, sy, sz, d2);
+            if (cp->dbg_idx5) G(cp->dbg_idx5)[5 * (size_t)o + j] = gatedA ? __float_as_int(m.w) : -1;
+            if (cp->dbg_d2) G(cp->dbg_d2)[5 * (size_t)o + j] = gatedA ? d2 : INFINITY;
         }
     }
-    sort5_u64(sk);
-    const bool meas_ok = had5 && key_hi(sk[4]) < 0x7f800000u;          // five finite distances
-    bool passB = false;
-    {
-        const float d2_5 = __uint_as_float(key_hi(sk[4]));
-        const float d5n = sqrtf(d2_5), r6n = r6o - eps;
-        passB = need && meas_ok && !(ablate & 2) && (d5n + kCertMargin < r6n) && ((double)d2_5 < cp->gate_sq);
-    }
-    const bool needC = need && !passB;
-    if (HOOK) { prof.n_b += __popcll(__ballot(passB)); prof.n_c += __popcll(__ballot(needC)); }
 
-    // ---- tier C: search, for the lanes that are left
-    Top5k best;
+    Top6k top;                                            // the outcome: the six nearest as (d2 | position), ascending
 #pragma unroll
-    for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
-    float bound = gatef;
-    float r6sq = 0.0f;                 // squared: no map point outside the final tuple is nearer than this (0: unknown)
-    bool far = false;                  // proved: fewer than 5 map points inside the gate
-    const unsigned long long cmask = __ballot(needC);
-    if (cmask) {
-        uint32_t tieb = 0xffffffffu;
-        if (needC && meas_ok && !(ablate & 16)) {                        // the re-measured tuple: 5 distinct map points, a valid upper bound
+    for (int k = 0; k < 6; k++) top.key[k] = kKeyInf;
+    float rn = 0.0f;                                      // every map point outside the evaluated neighbourhood is at least this far away
+    float r7 = 0.0f;                                      // ... and every one other than the six nearest at least this far
+    bool settled = false;                                 // the lane has its answer for this pose
+
+    // ---- tier B: the six nearest of the remembered neighbourhood, measured at this pose.  Everything outside it is at
+    // least r_out - (distance moved since) away: if that is beyond the new 5th member the tuple is proved; if it is
+    // beyond the gate and fewer than 5 members are inside the gate, "not gated" is proved.
+    {
+        const bool ev = need && nbr_ok && !(ablate & 2);
+        if (__ballot(ev)) {
+            const int nmax = wave_max_i32(ev ? nb_n : 0);
+            // A neighbourhood is stored with its six nearest members in front.  Those six first (positions, then the six
+            // reads - independent, 12 bytes each - then the insertions): they settle the lane on their own if everything
+            // else (>= r7o away at the reference position) is still beyond the 5th of them.  Only for lanes they do not
+            // settle are the other members read, and inserted only where some lane needs it.
+            Top6k t;
 #pragma unroll
-            for (int k = 0; k < 5; k++) best.key[k] = sk[k];
-            bound = fminf(__uint_as_float(key_hi(sk[4])), gatef);
+            for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
+            uint64_t k7 = kKeyInf;                         // the nearest of the members stored behind the first six
+            bool open = ev;                                // lanes not settled yet
+            {
+                int np_[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) { np_[k] = 0; if (ev && k < nb_n) np_[k] = nbrp[(size_t)k * nq + i]; }
+                v3f mm[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) mm[k] = *reinterpret_cast<gptr<const v3f>>(&map[np_[k]]);
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    const bool on = ev && k < nb_n;
+                    const float dx = sx - mm[k].x, dy = sy - mm[k].y, dz = sz - mm[k].z;
+                    const float d2 = (dx * dx + dy * dy) + dz * dz;                     // L2_Simple order
+                    top6k_insert(t, on ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)np_[k]) : kKeyInf);
+                }
+                const float r = r7o - eps;
+                const float d2_5 = __uint_as_float(key_hi(t.key[4]));
+                const bool in_gate = key_hi(t.key[4]) < 0x7f800000u && ((double)d2_5 < cp->gate_sq);
+                const bool ok = in_gate ? (sqrtf(d2_5) + kCertMargin < r) : (gate_r + kCertMargin < r);
+                if (open && ok) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) top.key[q] = t.key[q];
+                    rn = r_out - eps; r7 = r; settled = true; open = false;
+                }
+            }
+            if (__ballot(open) && nmax > 6) {
+                int np_[kNbr - 6];
+#pragma unroll
+                for (int k = 6; k < kNbr; k++) { np_[k - 6] = 0; if (k < nmax && open && k < nb_n) np_[k - 6] = nbrp[(size_t)k * nq + i]; }
+                v3f mm[kNbr - 6];
+#pragma unroll
+                for (int k = 6; k < kNbr; k++) {
+                    mm[k - 6] = v3f{ 0.0f, 0.0f, 0.0f };
+                    if (k < nmax) mm[k - 6] = *reinterpret_cast<gptr<const v3f>>(&map[np_[k - 6]]);
+                }
+#pragma unroll
+                for (int k = 6; k < kNbr; k++) {
+                    if (k < nmax) {                        // wave-uniform
+                        const bool on = open && k < nb_n;
+                        const float dx = sx - mm[k - 6].x, dy = sy - mm[k - 6].y, dz = sz - mm[k - 6].z;
+                        const float d2 = (dx * dx + dy * dy) + dz * dz;
+                        const uint64_t key = on ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)np_[k - 6]) : kKeyInf;
+                        k7 = (key < k7) ? key : k7;          // nearest of the members behind the six in front
+                        if (__ballot(key < t.key[5])) top6k_insert(t, key);
+                    }
+                }
+            }
+            if (__ballot(open)) {
+                const float r = r_out - eps;
+                const float d2_5 = __uint_as_float(key_hi(t.key[4]));
+                const bool in_gate = key_hi(t.key[4]) < 0x7f800000u && ((double)d2_5 < cp->gate_sq);
+                const bool ok = in_gate ? (sqrtf(d2_5) + kCertMargin < r) : (gate_r + kCertMargin < r);
+                if (open && ok) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) top.key[q] = t.key[q];
+                    rn = r; settled = true;
+                    // r7 keeps describing the six members IN FRONT of the stored list (whichever six are nearest now): everything
+                    // else is the other members, measured just now, and the outside
+                    r7 = (key_hi(k7) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(k7))) * 0.999999f, r) : r;
+                }
+            }
         }
+        if (HOOK) prof.n_b += __popcll(__ballot(settled));
+    }
+
+    // ================================ tier C: search =================================
+    const bool searching = need && !settled;
+    const unsigned long long cmask = __ballot(searching);
+    if (cmask) {
+        if (HOOK) prof.n_c += __popcll(cmask);
+        if (searching) { nb_n = 0; nbr_ok = false; }
+        // Upper bound of the 5th-neighbour distance: the old tuple measured at this pose (any 5 distinct map points would
+        // do), capped at the gate.
+        float bound = gatef;
+        Top5k best;                                        // only the fallback sweep uses it
+#pragma unroll
+        for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
+        if (searching && had5 && !(ablate & 16)) {
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                const v4f m = map[opos[j]];
+                float d2;
+                make_key(m, sx, sy, sz, d2);
+                top5k_insert(best, ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)opos[j]);
+            }
+            if (key_hi(best.key[4]) < 0x7f800000u) bound = fminf(__uint_as_float(key_hi(best.key[4])), gatef);
+            else {
+#pragma unroll
+                for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
+            }
+        }
+        const bool has_prior = searching && best.key[4] != kKeyInf;
         const int nC = __popcll(cmask);
         // wave bounding box of the searching lanes
-        const float mnx = wave_min_f32(needC ? sx : INFINITY), mxx = wave_max_f32(needC ? sx : -INFINITY);
-        const float mny = wave_min_f32(needC ? sy : INFINITY), mxy = wave_max_f32(needC ? sy : -INFINITY);
-        const float mnz = wave_min_f32(needC ? sz : INFINITY), mxz = wave_max_f32(needC ? sz : -INFINITY);
+        const float mnx = wave_min_f32(searching ? sx : INFINITY), mxx = wave_max_f32(searching ? sx : -INFINITY);
+        const float mny = wave_min_f32(searching ? sy : INFINITY), mxy = wave_max_f32(searching ? sy : -INFINITY);
+        const float mnz = wave_min_f32(searching ? sz : INFINITY), mxz = wave_max_f32(searching ? sz : -INFINITY);
 
         const int cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
         const int cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
@@ -270,7 +359,6 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         const int bz0 = max(cell_coord(mnz, g.oz, g.inv_e, g.nz) - 1, 0), bz1 = min(cell_coord(mxz, g.oz, g.inv_e, g.nz) + 1, g.nz - 1);
         const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
         const int R = nyb * nzb;                          // rows in the box
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);      // this lane's cells in a row
         if (HOOK) { prof.rows = R; prof.why = 0; }
 
         // squared slab distances of this query to the faces of its own cell: lower bounds of the
@@ -283,31 +371,28 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         const float gx2m = gxm * gxm * 0.9999f, gx2p = gxp * gxp * 0.9999f;
         const float gy2m = gym * gym * 0.9999f, gy2p = gyp * gyp * 0.9999f;
         const float gz2m = gzm * gzm * 0.9999f, gz2p = gzp * gzp * 0.9999f;
-        // How far this lane looks: kCertDelta beyond its bound, but not beyond what its 3x3x3 cells cover for certain
+        // How far this lane looks: a reach beyond its bound, but not beyond what its 3x3x3 cells cover for certain
         // (one whole cell past the nearest face of its own cell).  Every map point nearer than `be` is met.
         const float cover = (E - kSlabMargin) + fminf(fminf(fminf(gxm, gxp), fminf(gym, gyp)), fminf(gzm, gzp));
-        const float be = needC ? fminf(sqrtf(bound) + kCertDelta, cover) : 0.0f;
+        const float sb = sqrtf(bound);
+        const float be = searching ? fminf(sb + (has_prior ? kNbrReach : kNbrReachCold), cover) : 0.0f;
         const float be2 = fmaxf(be * be, bound);          // rows / cells are selected with this; never tighter than the bound itself
-        const float be2c = be * be * 0.99999f;            // what the certificate may rely on
-        const float rmax2 = wave_max_f32(needC ? be2 : 0.0f);
+        const float rmax2 = wave_max_f32(searching ? be2 : 0.0f);
 
         // ---- tile path: per group of 64 box rows, mark the rows some lane still needs, size them
-        // and stream them through the filter into the tile; gather only if the tile overflows.
+        // and stream them through the filter into the tile; the lanes are served one by one if the tile overflows.
         // A box far larger than the lanes' own neighbourhoods (scattered points) is not worth staging, and neither is
         // a tile for a handful of lanes.
         const int tile_cap = kTilePts;
         const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
         const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
-        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * nC && (nC > kGatherLanes || (ablate & 128));
+        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * nC && (nC > kServeLanes || (ablate & 128));
         if (HOOK && !tile) prof.why = 1;
-        int nt = 0, ntf = 0;                              // tile fill from the front (near) and the back (far), wave-uniform
-        const float wcx = 0.5f * (mnx + mxx), wcy = 0.5f * (mny + mxy), wcz = 0.5f * (mnz + mxz);
-        const float whd = 0.5f * sqrtf(((mxx - mnx) * (mxx - mnx) + (mxy - mny) * (mxy - mny)) + (mxz - mnz) * (mxz - mnz));
-        const float near2 = (whd + 0.45f) * (whd + 0.45f);
+        int nt = 0;                                       // tile fill, wave-uniform
         for (int rg = 0; rg < R && tile; rg += 64) {
             // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
             unsigned long long want = 0ull;
-            if (needC) {
+            if (searching) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
                     const int dyc = run_dy(k), dzc = run_dz(k);
@@ -356,207 +441,158 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                     pc_v.w = __int_as_float(gsc + k);
                     const bool ia = ha && pa_v.x >= fx0 && pa_v.x <= fx1 && pa_v.y >= fy0 && pa_v.y <= fy1 && pa_v.z >= fz0 && pa_v.z <= fz1;
                     const bool ic = hc && pc_v.x >= fx0 && pc_v.x <= fx1 && pc_v.y >= fy0 && pc_v.y <= fy1 && pc_v.z >= fz0 && pc_v.z <= fz1;
-                    // near the wave's centre -> front of the tile, the rest -> back: a full sweep then
-                    // meets every lane's likely neighbours first and its bound is tight for the remainder
-                    const float ax = pa_v.x - wcx, ay = pa_v.y - wcy, az = pa_v.z - wcz;
-                    const float bx = pc_v.x - wcx, by = pc_v.y - wcy, bz = pc_v.z - wcz;
-                    const bool na_ = (ax * ax + ay * ay) + az * az <= near2, nc_ = (bx * bx + by * by) + bz * bz <= near2;
-                    const unsigned long long man = __ballot(ia && na_), maf = __ballot(ia && !na_);
-                    const unsigned long long mcn = __ballot(ic && nc_), mcf = __ballot(ic && !nc_);
-                    const int an = __popcll(man), af = __popcll(maf), cn = __popcll(mcn), cf = __popcll(mcf);
-                    if (nt + ntf + an + af + cn + cf > tile_cap) { tile = false; if (HOOK) prof.why = 3; break; }
+                    const unsigned long long ma = __ballot(ia), mc = __ballot(ic);
+                    const int an = __popcll(ma), cn = __popcll(mc);
+                    if (nt + an + cn > tile_cap) { tile = false; if (HOOK) prof.why = 3; break; }
                     const unsigned long long below = (1ull << lane) - 1ull;
-                    if (ia) lpts[na_ ? nt + __popcll(man & below) : tile_cap - 1 - (ntf + __popcll(maf & below))] = pa_v;
-                    if (ic) lpts[nc_ ? nt + an + __popcll(mcn & below) : tile_cap - 1 - (ntf + af + __popcll(mcf & below))] = pc_v;
-                    nt += an + cn; ntf += af + cf;
+                    if (ia) lpts[nt + __popcll(ma & below)] = pa_v;
+                    if (ic) lpts[nt + an + __popcll(mc & below)] = pc_v;
+                    nt += an + cn;
                 }
             }
         }
 
-        bool glanes = false;                              // lanes that take the gather path
         if (tile) {
             wave_lds_sync();
-            if (HOOK) { prof.mode = 1; prof.pts = nt + ntf; }
-            // ---- verify: count the tile points with d2 <= bound and find the nearest one beyond it (branch-free).
-            //  - complete tuple and exactly 5 inside: no OTHER point lies within the tuple's 5th distance (its 5 points
-            //    are in the tile: their rows were marked and they pass the filter), so the tuple stands; the nearest
-            //    point beyond the bound is the 6th neighbour: r6 for the next certificate;
-            //  - bound is the gate and fewer than 5 inside: the point is not gated, whatever its neighbours are.
-            bool todo = needC;                            // lanes that still need a sweep
-            float tb = bound;                             // radius (squared) of this lane's candidate list ...
-            int ccnt = 0;                                 // ... and the number of tile points inside it
+            if (HOOK) { prof.mode = 1; prof.pts = nt; }
+            // The radii (squared) the tile points are counted against, widest first.  With a tuple to start from: from the
+            // reach down to the bound itself; without one: the reach, the gate, and fractions of the gate.  The neighbourhood
+            // becomes the widest of them that holds at most kNbr points.
+            float tl[kLevels];
+            if (has_prior) {
+                const float st[kLevels] = { kNbrReach, 0.10f, 0.06f, 0.03f, 0.012f, 0.0f };
+#pragma unroll
+                for (int k = 0; k < kLevels; k++) { const float rr_ = fminf(sb + st[k], be); tl[k] = fmaxf(rr_ * rr_, bound); }
+                tl[kLevels - 1] = bound;
+            } else {
+                const float fr[kLevels] = { 0.0f, 1.0f, 1.0f / 1.6f, 1.0f / 2.56f, 1.0f / 4.1f, 1.0f / 6.55f };
+#pragma unroll
+                for (int k = 0; k < kLevels; k++) tl[k] = fminf(gatef * fr[k], be2);
+                tl[0] = be2;
+            }
+            // ---- count the tile points inside the kLevels radii of every searching lane (branch-free)
+            int c[kLevels];
+#pragma unroll
+            for (int k = 0; k < kLevels; k++) c[k] = 0;
             {
-                // the stored tuple counts as a candidate answer only while all five of its points are inside the bound
-                const bool prior_ok = needC && best.key[4] != kKeyInf && __uint_as_float(key_hi(best.key[4])) <= bound;
-                // A wave of a split chunk holds 32, 16 or 8 points in its first lanes; when all of them search, the idle
-                // lanes join in: kq = 2, 4 or 8 lanes share a point, each counts every kq-th tile point, and the partial
-                // results are combined across the group.  (These short waves sit in dense parts of the map.)
-                // `cold`: some lane has no tuple (first launch of a scan).  Its bound is the gate, and a candidate list cut
-                // at the gate could be long; so the sweep counts against four radii at once (bound, /2, /4, /8) and each
-                // lane keeps the tightest one that still holds 5 points: tb, with ccnt points inside.
-                const bool cold = __ballot(needC && !prior_ok) != 0ull;
-                const bool packed = cmask == ((chunk.y >= 64) ? ~0ull : ((1ull << chunk.y) - 1ull));
-                const int kq = (cold || !packed) ? 1 : ((chunk.y > 32) ? 1 : ((chunk.y > 16) ? 2 : ((chunk.y > 8) ? 4 : 8)));
-                const int nslot = 64 / kq, part = lane / nslot;
-                float qx_ = sx, qy_ = sy, qz_ = sz, qb_ = bound;
-                if (kq > 1) {
-                    const int src = lane & (nslot - 1);
-                    qx_ = __shfl(sx, src, 64); qy_ = __shfl(sy, src, 64); qz_ = __shfl(sz, src, 64); qb_ = __shfl(bound, src, 64);
+                int j = 0;
+                for (; j + 2 <= nt; j += 2) {                 // two LDS reads in flight
+                    const v4f m0 = lpts[j], m1 = lpts[j + 1];
+                    float d0, d1;
+                    make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+#pragma unroll
+                    for (int k = 0; k < kLevels; k++) c[k] += ((d0 <= tl[k]) ? 1 : 0) + ((d1 <= tl[k]) ? 1 : 0);
                 }
-                int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-                float m6 = INFINITY;                       // nearest tile point beyond the bound
-                if (cold) {
-                    const float t1 = bound * 0.5f, t2 = bound * 0.25f, t3 = bound * 0.125f;
-                    for (int seg = 0; seg < 2; seg++) {
-                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                        int j = jb;
-                        for (; j + 4 <= je; j += 4) {         // four LDS reads in flight
-                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                            float d0, d1, d2v, d3;
-                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                            c0 += ((d0 <= bound) ? 1 : 0) + ((d1 <= bound) ? 1 : 0) + ((d2v <= bound) ? 1 : 0) + ((d3 <= bound) ? 1 : 0);
-                            c1 += ((d0 <= t1) ? 1 : 0) + ((d1 <= t1) ? 1 : 0) + ((d2v <= t1) ? 1 : 0) + ((d3 <= t1) ? 1 : 0);
-                            c2 += ((d0 <= t2) ? 1 : 0) + ((d1 <= t2) ? 1 : 0) + ((d2v <= t2) ? 1 : 0) + ((d3 <= t2) ? 1 : 0);
-                            c3 += ((d0 <= t3) ? 1 : 0) + ((d1 <= t3) ? 1 : 0) + ((d2v <= t3) ? 1 : 0) + ((d3 <= t3) ? 1 : 0);
-                            m6 = fminf(fminf(m6, (d0 > bound) ? d0 : INFINITY), (d1 > bound) ? d1 : INFINITY);
-                            m6 = fminf(fminf(m6, (d2v > bound) ? d2v : INFINITY), (d3 > bound) ? d3 : INFINITY);
-                        }
-                        for (; j < je; j++) {
-                            float d; make_key(lpts[j], sx, sy, sz, d);
-                            c0 += (d <= bound) ? 1 : 0; c1 += (d <= t1) ? 1 : 0; c2 += (d <= t2) ? 1 : 0; c3 += (d <= t3) ? 1 : 0;
-                            m6 = fminf(m6, (d > bound) ? d : INFINITY);
-                        }
-                    }
-                    tb = (c3 >= 5) ? t3 : ((c2 >= 5) ? t2 : ((c1 >= 5) ? t1 : bound));
-                    ccnt = (c3 >= 5) ? c3 : ((c2 >= 5) ? c2 : ((c1 >= 5) ? c1 : c0));
-                    c1 = 0; c2 = 0; c3 = 0;               // c0 = points inside `bound`, as in the other branches
-                } else if (kq == 1) {                     // the common case, with compile-time LDS offsets
-                    float ma = INFINITY, mb = INFINITY;
-                    for (int seg = 0; seg < 2; seg++) {
-                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                        int j = jb;
-                        for (; j + 4 <= je; j += 4) {
-                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                            float d0, d1, d2v, d3;
-                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                            c0 += (d0 <= bound) ? 1 : 0; c1 += (d1 <= bound) ? 1 : 0;
-                            c2 += (d2v <= bound) ? 1 : 0; c3 += (d3 <= bound) ? 1 : 0;
-                            ma = fminf(fminf(ma, (d0 > bound) ? d0 : INFINITY), (d1 > bound) ? d1 : INFINITY);
-                            mb = fminf(fminf(mb, (d2v > bound) ? d2v : INFINITY), (d3 > bound) ? d3 : INFINITY);
-                        }
-                        for (; j < je; j++) {
-                            float d; make_key(lpts[j], sx, sy, sz, d);
-                            c0 += (d <= bound) ? 1 : 0;
-                            ma = fminf(ma, (d > bound) ? d : INFINITY);
-                        }
-                    }
-                    m6 = fminf(ma, mb);
-                } else {
-                    for (int seg = 0; seg < 2; seg++) {
-                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                        int j = jb + part;
-                        for (; j + 3 * kq < je; j += 4 * kq) {
-                            const v4f m0 = lpts[j], m1 = lpts[j + kq], m2 = lpts[j + 2 * kq], m3 = lpts[j + 3 * kq];
-                            float d0, d1, d2v, d3;
-                            make_key(m0, qx_, qy_, qz_, d0); make_key(m1, qx_, qy_, qz_, d1);
-                            make_key(m2, qx_, qy_, qz_, d2v); make_key(m3, qx_, qy_, qz_, d3);
-                            c0 += (d0 <= qb_) ? 1 : 0; c1 += (d1 <= qb_) ? 1 : 0;
-                            c2 += (d2v <= qb_) ? 1 : 0; c3 += (d3 <= qb_) ? 1 : 0;
-                            m6 = fminf(fminf(m6, (d0 > qb_) ? d0 : INFINITY), (d1 > qb_) ? d1 : INFINITY);
-                            m6 = fminf(fminf(m6, (d2v > qb_) ? d2v : INFINITY), (d3 > qb_) ? d3 : INFINITY);
-                        }
-                        for (; j < je; j += kq) {
-                            float d; make_key(lpts[j], qx_, qy_, qz_, d);
-                            c0 += (d <= qb_) ? 1 : 0;
-                            m6 = fminf(m6, (d > qb_) ? d : INFINITY);
-                        }
-                    }
-                }
-                int cnt = c0 + c1 + c2 + c3;
-                for (int m = nslot; m < 64; m <<= 1) { cnt += __shfl_xor(cnt, m, 64); m6 = fminf(m6, __shfl_xor(m6, m, 64)); }
-                if (!cold) ccnt = cnt;
-                if (prior_ok && cnt == 5) { todo = false; r6sq = fminf(m6, be2c); }
-                else if (needC && bound >= gatef && cnt < 5) { todo = false; far = true; r6sq = fminf(m6, be2c); }
-            }
-            // ---- lanes with a new, lost or missing neighbour.  The insertion network is a few dozen VALU and a wave
-            // pays it whenever ANY lane inserts, i.e. at nearly every tile point; so the lanes first write down
-            // the tile positions inside tb (a second branch-free sweep; exactly ccnt of them, >= 5 by
-            // construction, so the 5 nearest are among them) and then insert their k-th candidates together:
-            // ~10 wave-wide insertions instead of one per tile point.
-            if (__ballot(todo)) {
-                const bool use_list = todo && ccnt <= kCand;
-                if (__ballot(use_list)) {
-                    int cc = 0;
-                    if (use_list) {
-                        for (int seg = 0; seg < 2; seg++) {
-                            const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                            int j = jb;
-                            for (; j + 4 <= je; j += 4) {     // four LDS reads in flight
-                                const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                                float d0, d1, d2v, d3;
-                                make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                                make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                                if (d0 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
-                                if (d1 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 1); cc++; }
-                                if (d2v <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 2); cc++; }
-                                if (d3 <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)(j + 3); cc++; }
-                            }
-                            for (; j < je; j++) {
-                                float d; make_key(lpts[j], sx, sy, sz, d);
-                                if (d <= tb && cc < kCand) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
-                            }
-                        }
-                    }
-                    wave_lds_sync();
-                    const int cmax = wave_max_i32(cc);
-                    // candidate k+1 is fetched while candidate k is inserted; slots past cc hold stale positions (clamped, unused)
-                    v4f mk = lpts[min((int)lcand[lane], kTilePts - 1)];
-                    for (int k = 0; k < cmax; k++) {
-                        const v4f mn_ = lpts[min((int)lcand[min(k + 1, kCand - 1) * 64 + lane], kTilePts - 1)];
-                        if (k < cc) consider(best, bound, gatef, tieb, mk, sx, sy, sz);
-                        mk = mn_;
-                    }
-                    todo = todo && !use_list;
+                for (; j < nt; j++) {
+                    float d; make_key(lpts[j], sx, sy, sz, d);
+#pragma unroll
+                    for (int k = 0; k < kLevels; k++) c[k] += (d <= tl[k]) ? 1 : 0;
                 }
             }
-            // ---- full sweep for whoever is left (a candidate list that would not fit): the tile, near segment first
-            if (__ballot(todo)) {
-                if (todo) {
-                    for (int seg = 0; seg < 2; seg++) {
-                        const int jb = seg ? tile_cap - ntf : 0, je = seg ? tile_cap : nt;
-                        int j = jb;
-                        for (; j + 4 <= je; j += 4) {
-                            const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                            consider(best, bound, gatef, tieb, m0, sx, sy, sz);
-                            consider(best, bound, gatef, tieb, m1, sx, sy, sz);
-                            consider(best, bound, gatef, tieb, m2, sx, sy, sz);
-                            consider(best, bound, gatef, tieb, m3, sx, sy, sz);
-                        }
-                        for (; j < je; j++) consider(best, bound, gatef, tieb, lpts[j], sx, sy, sz);
+            // the widest level that fits; it has to hold the tuple (5 points) unless even the gate holds fewer than 5
+            // (a tuple to start from whose 5th member is beyond the gate has bound = gate: the last level counts the gate)
+            int cl = c[kLevels - 1];
+            float lvl2 = tl[kLevels - 1];
+#pragma unroll
+            for (int k = kLevels - 2; k >= 0; k--) { const bool fits = c[k] <= kNbr; lvl2 = fits ? tl[k] : lvl2; cl = fits ? c[k] : cl; }
+            const int c_gate = has_prior ? c[kLevels - 1] : c[1];
+            const bool fallback = searching && (cl > kNbr || (cl < 5 && c_gate >= 5));
+            // ---- the neighbourhood: tile slots inside the level, written down in a second branch-free sweep
+            const bool lister = searching && !fallback;
+            int cc = 0;
+            if (lister) {
+                int j = 0;
+                for (; j + 4 <= nt; j += 4) {                 // four LDS reads in flight
+                    const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                    float d0, d1, d2v, d3;
+                    make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                    make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                    if (d0 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
+                    if (d1 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 1); cc++; }
+                    if (d2v <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 2); cc++; }
+                    if (d3 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 3); cc++; }
+                }
+                for (; j < nt; j++) {
+                    float d; make_key(lpts[j], sx, sy, sz, d);
+                    if (d <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
+                }
+            }
+            wave_lds_sync();
+            // ---- its six nearest (the lanes insert their k-th member together), then the neighbourhood goes to memory with
+            // those six in front
+            {
+                const int cmax = wave_max_i32(cc);
+                Top6k t;
+#pragma unroll
+                for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
+                uint64_t k7 = kKeyInf;
+                v4f mk = lpts[min((int)lcand[lane], kTilePts - 1)];
+                for (int k = 0; k < cmax; k++) {
+                    const v4f mn_ = lpts[min((int)lcand[min(k + 1, kCand - 1) * 64 + lane], kTilePts - 1)];
+                    float d2;
+                    const uint64_t key = make_key(mk, sx, sy, sz, d2);
+                    const uint64_t out = top6k_insert(t, (lister && k < cc) ? key : kKeyInf);
+                    k7 = (out < k7) ? out : k7;
+                    mk = mn_;
+                }
+                if (lister) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) top.key[k] = t.key[k];
+                    nb_n = cc; rn = sqrtf(lvl2) * 0.999999f; nbr_ok = true; settled = true;
+                    r7 = (key_hi(k7) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(k7))), rn) : rn;
+                    int slot = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++)
+                        if (key_hi(t.key[k]) < 0x7f800000u) { nbrp[(size_t)slot * nq + i] = (int)key_lo(t.key[k]); slot++; }
+                    for (int k = 0; k < cc; k++) {
+                        const int p = __float_as_int(lpts[min((int)lcand[k * 64 + lane], kTilePts - 1)].w);
+                        bool in6 = false;
+#pragma unroll
+                        for (int j = 0; j < 6; j++) in6 = in6 || (uint32_t)p == key_lo(t.key[j]);
+                        if (!in6 && slot < kNbr) { nbrp[(size_t)slot * nq + i] = p; slot++; }
                     }
+                }
+            }
+            // ---- fallback: the exact top-5 by a full sweep of the tile (no neighbourhood: the lane searches again next time)
+            if (__ballot(fallback)) {
+                uint32_t tieb = 0xffffffffu;
+                if (fallback) {
+                    int j = 0;
+                    for (; j + 4 <= nt; j += 4) {
+                        const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+                        consider(best, bound, gatef, tieb, m0, sx, sy, sz);
+                        consider(best, bound, gatef, tieb, m1, sx, sy, sz);
+                        consider(best, bound, gatef, tieb, m2, sx, sy, sz);
+                        consider(best, bound, gatef, tieb, m3, sx, sy, sz);
+                    }
+                    for (; j < nt; j++) consider(best, bound, gatef, tieb, lpts[j], sx, sy, sz);
+                    if (best.key[4] != kKeyInf && tieb == key_hi(best.key[4]))
+                        exact_top5_of_cells(map, cell_start, g, cx, cy, cz, sx, sy, sz, gatef, best);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) top.key[k] = best.key[k];
+                    top.key[5] = kKeyInf;
+                    // every point within the bound was considered (members of a stale tuple beyond it may linger in the set:
+                    // such a lane is not gated, and nothing is known beyond the bound)
+                    rn = sqrtf(fminf(bound, be2)) * 0.999999f; r7 = rn;
+                    settled = true;
                 }
             }
         }
-        if (!tile) glanes = needC;
-        // ---- serve: the whole wave works for one searching lane at a time.  Lanes 0..8 size the lane's (<= 9) x-runs,
-        // the candidates (all map points of those cells) are read 64 at a time, their keys kept in the wave's LDS area,
-        // counted against the lane's bound like in the tile path; only when the tuple did change, six rounds of
-        // "smallest key above the last one" pick the new tuple and the 6th neighbour (r6 for the certificate).
-        // ~2 dependent round trips per served lane instead of one per run: a handful of lanes left over in a late
-        // launch costs a few microseconds, not the 20 of a lane walking its runs alone.
-        if (__ballot(glanes)) {
-            if (HOOK) prof.mode = tile ? 3 : 2;
+        // ---- serve: the whole wave works for one searching lane at a time.  Lanes 0..8 size the lane's (<= 9) x-runs, the
+        // candidates (all map points of those cells) are read 64 at a time, their keys kept in the wave's LDS area, and seven
+        // rounds of "smallest key above the last one" pick the six nearest and the distance of the seventh: the lane's new
+        // neighbourhood and its radius.  ~2 dependent round trips per served lane.
+        unsigned long long pend = (tile || nC > kWalkLanes) ? 0ull : cmask;
+        unsigned long long walk = (!tile && nC > kWalkLanes) ? cmask : 0ull;      // lanes that walk their own cells (below)
+        if (pend) {
+            if (HOOK) prof.mode = (prof.why >= 2) ? 3 : 2;
             uint64_t* lkeys = reinterpret_cast<uint64_t*>(lpts);
             constexpr int kServeCap = kTilePts * 2;           // u64 keys that fit the tile area
-            unsigned long long pend = __ballot(glanes);
-            unsigned long long walk = 0ull;                    // lanes whose candidates did not fit: they walk their runs below
             while (pend) {
                 const int L = (int)__builtin_ctzll(pend);
                 pend &= pend - 1ull;
                 const float qsx = lane_bcast(sx, L), qsy = lane_bcast(sy, L), qsz = lane_bcast(sz, L);
-                const float qb = lane_bcast(bound, L), qe2 = lane_bcast(be2, L);
+                const float qe2 = lane_bcast(be2, L);
                 const int qcx = __builtin_amdgcn_readlane(cx, L), qcy = __builtin_amdgcn_readlane(cy, L), qcz = __builtin_amdgcn_readlane(cz, L);
                 const float qy2m = lane_bcast(gy2m, L), qy2p = lane_bcast(gy2p, L), qz2m = lane_bcast(gz2m, L), qz2p = lane_bcast(gz2p, L);
                 const float qx2m = lane_bcast(gx2m, L), qx2p = lane_bcast(gx2p, L);
@@ -575,13 +611,10 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 }
                 const int incl = wave_incl_scan_i32(rl);
                 const int P = __builtin_amdgcn_readlane(incl, 63);
-                if (P > kServeCap) { walk |= 1ull << L; continue; }
+                if (P > kServeCap) { walk |= 1ull << L; continue; }                   // more candidates than the LDS area holds
                 int rst[9], rpe[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) { rst[k] = __builtin_amdgcn_readlane(rs, k); rpe[k] = __builtin_amdgcn_readlane(incl, k); }
-                // phase 1: keys into LDS, count inside the bound, nearest beyond it
-                int cnt = 0;
-                float m6 = INFINITY;
                 for (int base = 0; base < P; base += 64) {
                     const int t = base + lane;
                     int off = rst[0];
@@ -591,194 +624,104 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                         v4f m = map[t + off];
                         m.w = __int_as_float(t + off);
                         float d2;
-                        const uint64_t key = make_key(m, qsx, qsy, qsz, d2);
-                        lkeys[t] = key;
-                        cnt += (d2 <= qb) ? 1 : 0;
-                        m6 = fminf(m6, (d2 > qb) ? d2 : INFINITY);
+                        lkeys[t] = make_key(m, qsx, qsy, qsz, d2);
                     }
                 }
                 if (HOOK) prof.pts += P;
-                cnt = __builtin_amdgcn_readlane(wave_incl_scan_i32(cnt), 63);
-                m6 = wave_min_f32(m6);
-                const uint64_t k5 = __shfl(best.key[4], L, 64);                 // wave-uniform copy of the served lane's 5th key
-                const bool prior_ok = k5 != kKeyInf && __uint_as_float(key_hi(k5)) <= qb;
-                if (prior_ok && cnt == 5) {
-                    if (lane == L) r6sq = fminf(m6, be2c);
-                } else if (qb >= gatef && cnt < 5) {
-                    if (lane == L) { far = true; r6sq = fminf(m6, be2c); }
-                } else {
-                    // phase 2: the six smallest keys, one per round
-                    wave_lds_sync();
-                    uint64_t last = 0ull, found[6];
+                wave_lds_sync();
+                uint64_t last = 0ull, found[7];
+#pragma unroll
+                for (int r = 0; r < 7; r++) {
+                    uint64_t mine = kKeyInf | 0xffffffffull;                 // above every real key
+                    for (int t = lane; t < P; t += 64) {
+                        const uint64_t k = lkeys[t];
+                        const bool cnd = (r == 0 || k > last) && k < mine;
+                        mine = cnd ? k : mine;
+                    }
+                    // 64-bit minimum over the wave: distance word first, position word among its holders
+                    const uint32_t hmin = wave_min_u32(key_hi(mine));
+                    const uint32_t lmin = wave_min_u32(key_hi(mine) == hmin ? key_lo(mine) : 0xffffffffu);
+                    last = ((uint64_t)hmin << 32) | lmin;
+                    found[r] = last;
+                }
+                if (lane == L) {
+                    // members: the nearest six that lie inside what the walked cells cover for certain; the radius: the 7th, or that rim
+                    const float rim2 = be * be * 0.99999f;
+                    int n6 = 0;
 #pragma unroll
                     for (int r = 0; r < 6; r++) {
-                        uint64_t mine = kKeyInf | 0xffffffffull;                 // above every real key
-                        for (int t = lane; t < P; t += 64) {
-                            const uint64_t k = lkeys[t];
-                            const bool c = (r == 0 || k > last) && k < mine;
-                            mine = c ? k : mine;
-                        }
-                        // 64-bit minimum over the wave: distance word first, position word among its holders
-                        const uint32_t hmin = wave_min_u32(key_hi(mine));
-                        const uint32_t lmin = wave_min_u32(key_hi(mine) == hmin ? key_lo(mine) : 0xffffffffu);
-                        last = ((uint64_t)hmin << 32) | lmin;
-                        found[r] = last;
+                        const bool have = key_hi(found[r]) < 0x7f800000u && __uint_as_float(key_hi(found[r])) <= rim2;
+                        top.key[r] = have ? found[r] : kKeyInf;
+                        n6 += have ? 1 : 0;
+                        if (have) nbrp[(size_t)r * nq + i] = (int)key_lo(found[r]);
                     }
-                    if (lane == L) {
-#pragma unroll
-                        for (int r = 0; r < 5; r++) {
-                            const bool have = key_hi(found[r]) < 0x7f800000u && __uint_as_float(key_hi(found[r])) <= qb;
-                            best.key[r] = have ? found[r] : kKeyInf;
-                        }
-                        const bool six = key_hi(found[5]) < 0x7f800000u;
-                        r6sq = best.key[4] != kKeyInf ? fminf(six ? __uint_as_float(key_hi(found[5])) : INFINITY, be2c) : 0.0f;
-                        if (six && key_hi(found[5]) == key_hi(found[4])) tieb = key_hi(found[4]);   // 5th and 6th at the same distance
-                        bound = fminf(__uint_as_float(key_hi(best.key[4])), gatef);
-                    }
+                    const bool seven = n6 == 6 && key_hi(found[6]) < 0x7f800000u;
+                    rn = sqrtf(fminf(seven ? __uint_as_float(key_hi(found[6])) : INFINITY, rim2)) * 0.999999f;
+                    nb_n = n6; nbr_ok = true; settled = true; r7 = rn;
                 }
                 wave_lds_sync();                                  // the next lane's keys go to the same LDS area
             }
-            glanes = glanes && ((walk >> lane) & 1ull) != 0ull;
         }
-        if (__ballot(glanes)) {
-            // ---- gather: run bounds of all 9 rows first (independent loads, kept in LDS), then the runs
-            int32_t (*lrun)[64] = reinterpret_cast<int32_t (*)[64]>(lpts);
-            if (glanes) {
-                int rs[9], re[9];
+        // ---- lanes left to walk their own 3x3x3 cells (a tile that overflowed under many lanes, or more candidates than the
+        // served path holds): exact, slow, and without a neighbourhood - the point searches again next launch
+        const bool walker = searching && ((walk >> lane) & 1ull) != 0ull;
+        if (__ballot(walker)) {
+            if (HOOK) prof.mode = 3;
+            if (walker) {
+                exact_top5_of_cells(map, cell_start, g, cx, cy, cz, sx, sy, sz, gatef, best);
 #pragma unroll
-                for (int k = 0; k < 9; k++) {
-                    const int dyc = run_dy(k), dzc = run_dz(k);
-                    const int yy = cy + dyc, zz = cz + dzc;
-                    const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                    rs[k] = 0; re[k] = 0;
-                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > be2)) {
-                        const int xs = (x0 < cx && lb + gx2m <= be2) ? x0 : cx;     // left cell still reachable?
-                        const int xe = (x1 > cx && lb + gx2p <= be2) ? x1 : cx;     // right cell?
-                        const int rb = (zz * g.ny + yy) * g.nx;
-                        rs[k] = cell_start[rb + xs];
-                        re[k] = cell_start[rb + xe + 1];
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) { lrun[2 * k][lane] = rs[k]; lrun[2 * k + 1][lane] = re[k]; }
+                for (int k = 0; k < 5; k++) top.key[k] = best.key[k];
+                top.key[5] = kKeyInf;
+                rn = (best.key[4] != kKeyInf) ? sqrtf(__uint_as_float(key_hi(best.key[4]))) : gate_r; r7 = rn;
+                settled = true;
             }
-            wave_lds_sync();
-            if (glanes) {
-                // ---- verify first (same argument as in the tile path): count this lane's candidates with d2 <= bound
-                // and find the nearest one beyond, branch-free.  The first 4 points of run k+1 are in flight while run k
-                // is counted.  The key's low word is the position: set from the loop index.
-                bool full_pass = true;
-                {
-                    const bool prior_ok = best.key[4] != kKeyInf && __uint_as_float(key_hi(best.key[4])) <= bound;
-                    int cnt = 0;
-                    float m6 = INFINITY;
-                    int jn = lrun[0][lane], en = lrun[1][lane];
-                    v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
-                    if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-#pragma unroll 1
-                    for (int k = 0; k < 9; k++) {
-                        const int j0 = jn, e = en;
-                        const v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
-                        if (k < 8) {
-                            jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
-                            if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-                        }
-                        if (j0 < e) {
-                            float d0, d1, d2v, d3;
-                            make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                            make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
-                            cnt += (d0 <= bound) ? 1 : 0;
-                            cnt += (j0 + 1 < e && d1 <= bound) ? 1 : 0;          // past the end the last point was re-read
-                            cnt += (j0 + 2 < e && d2v <= bound) ? 1 : 0;
-                            cnt += (j0 + 3 < e && d3 <= bound) ? 1 : 0;
-                            m6 = fminf(fminf(m6, (d0 > bound) ? d0 : INFINITY), (d1 > bound) ? d1 : INFINITY);
-                            m6 = fminf(fminf(m6, (d2v > bound) ? d2v : INFINITY), (d3 > bound) ? d3 : INFINITY);
-                            if (HOOK) prof.pts += e - j0;
-                            for (int j = j0 + 4; j < e; j += 4) {                  // long runs: 4 loads in flight
-                                const v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
-                                make_key(q0, sx, sy, sz, d0); make_key(q1, sx, sy, sz, d1);
-                                make_key(q2, sx, sy, sz, d2v); make_key(q3, sx, sy, sz, d3);
-                                cnt += (d0 <= bound) ? 1 : 0;
-                                cnt += (j + 1 < e && d1 <= bound) ? 1 : 0;
-                                cnt += (j + 2 < e && d2v <= bound) ? 1 : 0;
-                                cnt += (j + 3 < e && d3 <= bound) ? 1 : 0;
-                                m6 = fminf(fminf(m6, (d0 > bound) ? d0 : INFINITY), (d1 > bound) ? d1 : INFINITY);
-                                m6 = fminf(fminf(m6, (d2v > bound) ? d2v : INFINITY), (d3 > bound) ? d3 : INFINITY);
-                            }
-                        }
-                    }
-                    if (prior_ok && cnt == 5) { full_pass = false; r6sq = fminf(m6, be2c); }
-                    else if (bound >= gatef && cnt < 5) { full_pass = false; far = true; r6sq = fminf(m6, be2c); }
-                }
-                // ---- full pass for the lanes that gained, lost or lack a neighbour (lines now L2-warm)
-                if (full_pass) {
-                    int jn = lrun[0][lane], en = lrun[1][lane];
-                    v4f n0 = { 0, 0, 0, 0 }, n1 = n0, n2 = n0, n3 = n0;
-                    if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-#pragma unroll 1
-                    for (int k = 0; k < 9; k++) {
-                        const int j0 = jn, e = en;
-                        v4f m0 = n0, m1 = n1, m2 = n2, m3 = n3;
-                        if (k < 8) {
-                            jn = lrun[2 * k + 2][lane]; en = lrun[2 * k + 3][lane];
-                            if (jn < en) { n0 = map[jn]; n1 = map[min(jn + 1, en - 1)]; n2 = map[min(jn + 2, en - 1)]; n3 = map[min(jn + 3, en - 1)]; }
-                        }
-                        const int dyc = run_dy(k), dzc = run_dz(k);
-                        const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
-                        if (j0 < e && !(lb > bound)) {                                 // bound may have tightened meanwhile
-                            m0.w = __int_as_float(j0); m1.w = __int_as_float(min(j0 + 1, e - 1));
-                            m2.w = __int_as_float(min(j0 + 2, e - 1)); m3.w = __int_as_float(min(j0 + 3, e - 1));
-                            consider(best, bound, gatef, tieb, m0, sx, sy, sz);
-                            consider(best, bound, gatef, tieb, m1, sx, sy, sz);
-                            consider(best, bound, gatef, tieb, m2, sx, sy, sz);
-                            consider(best, bound, gatef, tieb, m3, sx, sy, sz);
-                            for (int j = j0 + 4; j < e; j += 4) {                      // long runs: 4 loads in flight
-                                v4f q0 = map[j], q1 = map[min(j + 1, e - 1)], q2 = map[min(j + 2, e - 1)], q3 = map[min(j + 3, e - 1)];
-                                q0.w = __int_as_float(j); q1.w = __int_as_float(min(j + 1, e - 1));
-                                q2.w = __int_as_float(min(j + 2, e - 1)); q3.w = __int_as_float(min(j + 3, e - 1));
-                                consider(best, bound, gatef, tieb, q0, sx, sy, sz);
-                                consider(best, bound, gatef, tieb, q1, sx, sy, sz);
-                                consider(best, bound, gatef, tieb, q2, sx, sy, sz);
-                                consider(best, bound, gatef, tieb, q3, sx, sy, sz);
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        // ---- a tie across the 5th/6th boundary: the exact walk decides who is fifth
-        const bool tied = needC && !far && best.key[4] != kKeyInf && tieb == key_hi(best.key[4]);
-        if (__ballot(tied)) {
-            if (tied) { exact_top5_of_cells(map, cell_start, g, cx, cy, cz, sx, sy, sz, gatef, best); r6sq = 0.0f; }
         }
     }
 
     // ---- the outcome for every lane that re-measured or searched
-    const bool upd = passB || needC;
-    uint64_t fk[5];
+    const bool upd = need && settled;
+    uint64_t fk[6];
 #pragma unroll
-    for (int k = 0; k < 5; k++) fk[k] = passB ? sk[k] : best.key[k];
-    const bool complete = upd && !far && key_hi(fk[4]) < 0x7f800000u;
+    for (int k = 0; k < 6; k++) fk[k] = top.key[k];
+    bool tie56 = false;
+    {   // The 5th and the 6th at bit-identical distance: more points may stand at that distance than the six kept, and the
+        // reference order among them is by ORIGINAL index - the exact walk over the lane's cells decides (rare).
+        const bool btie = upd && key_hi(fk[4]) < 0x7f800000u && key_hi(fk[4]) == key_hi(fk[5]);
+        if (__ballot(btie)) {
+            if (btie) {
+                Top5k ex;
+                exact_top5_of_cells(map, cell_start, g, cell_coord(sx, g.ox, g.inv_e, g.nx), cell_coord(sy, g.oy, g.inv_e, g.ny),
+                                    cell_coord(sz, g.oz, g.inv_e, g.nz), sx, sy, sz, gatef, ex);
+                if (ex.key[4] != kKeyInf) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) fk[k] = ex.key[k];
+                }
+                fk[5] = kKeyInf;                           // (whoever is sixth stands at the 5th distance: no slack, see below)
+            }
+        }
+        tie56 = btie;
+    }
+    const bool complete = upd && key_hi(fk[4]) < 0x7f800000u;
     bool changed = !had5;
 #pragma unroll
     for (int k = 0; k < 5; k++) changed = changed || ((int)key_lo(fk[k]) != opos[k]);
-    // coordinates + original indices of the final tuple (L2-warm): unconditional so that nothing of the
-    // re-measuring above has to stay in registers across the search
-    v4f nb[5];
+    // coordinates + original indices of the six nearest (L2-warm)
+    v4f nb[6];
 #pragma unroll
-    for (int k = 0; k < 5; k++) nb[k] = map[complete ? (int)key_lo(fk[k]) : 0];
-    {   // equal distances inside the tuple: the reference order is (d2, ORIGINAL index)
+    for (int k = 0; k < 6; k++) nb[k] = map[(upd && key_hi(fk[k]) < 0x7f800000u) ? (int)key_lo(fk[k]) : 0];
+    {   // equal distances: the reference order is (d2, ORIGINAL index)
         bool tie_adj = false;
 #pragma unroll
-        for (int k = 0; k < 4; k++) tie_adj = tie_adj || (key_hi(fk[k]) == key_hi(fk[k + 1]));
-        tie_adj = tie_adj && complete;
+        for (int k = 0; k < 5; k++) tie_adj = tie_adj || (key_hi(fk[k]) == key_hi(fk[k + 1]) && key_hi(fk[k]) < 0x7f800000u);
+        tie_adj = tie_adj && upd;
         if (__ballot(tie_adj)) {
             if (tie_adj) {
 #pragma unroll
-                for (int pass = 0; pass < 4; pass++)
+                for (int pass = 0; pass < 5; pass++)
 #pragma unroll
-                    for (int k = 0; k < 4 - pass; k++) {
-                        const bool c = key_hi(fk[k]) == key_hi(fk[k + 1]) && __float_as_int(nb[k].w) > __float_as_int(nb[k + 1].w);
+                    for (int k = 0; k < 5 - pass; k++) {
+                        const bool c = key_hi(fk[k]) == key_hi(fk[k + 1]) && key_hi(fk[k]) < 0x7f800000u &&
+                                       __float_as_int(nb[k].w) > __float_as_int(nb[k + 1].w);
                         const uint64_t tk = fk[k]; fk[k] = c ? fk[k + 1] : tk; fk[k + 1] = c ? tk : fk[k + 1];
                         const v4f tn = nb[k]; nb[k] = c ? nb[k + 1] : tn; nb[k + 1] = c ? tn : nb[k + 1];
                     }
@@ -818,26 +761,29 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             planep[i] = pl;
             pst = 0;
         }
-        // the certificate for the launches to come
-        float slack = 0.0f, r6 = 0.0f;
-        if (far) {
-            r6 = sqrtf(r6sq);
-            slack = r6 - cp->gate_r - 2.0f * kCertMargin;                             // stays "fewer than 5 inside the gate"
-        } else if (complete) {
+        // the certificate for the launches to come: d1..d5, then the nearest of anything else - the 6th member of the
+        // neighbourhood or its rim
+        float slack = 0.0f;
+        const float rest = fminf(r7, rn);                 // everything that is not one of the six keys is at least this far away
+        const float d6 = (key_hi(fk[5]) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(fk[5]))), rest) : rest;
+        if (gated) {
             float dk[5];
 #pragma unroll
             for (int k = 0; k < 5; k++) dk[k] = sqrtf(__uint_as_float(key_hi(fk[k])));
-            r6 = passB ? (r6o - eps) : ((r6sq > 0.0f) ? sqrtf(r6sq) : dk[4]);
-            float gap = r6 - dk[4];
+            float gap = d6 - dk[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) gap = fminf(gap, dk[k + 1] - dk[k]);
-            slack = 0.5f * gap - kCertMargin;
-            slack = gated ? fminf(slack, cp->gate_r - dk[4] - 2.0f * kCertMargin) : 0.0f;
+            slack = fminf(0.5f * gap - kCertMargin, gate_r - dk[4] - 2.0f * kCertMargin);
+        } else {
+            // not gated: stays so while the 5th nearest map point (a member beyond the gate, or something outside the
+            // neighbourhood) cannot come inside the gate
+            const float f5 = complete ? fminf(sqrtf(d2_5), rest) : rest;
+            slack = f5 - gate_r - 2.0f * kCertMargin;
         }
-        slack = (slack > 0.0f) ? slack : 0.0f;                                        // also NaN -> 0
+        slack = (slack > 0.0f && !tie56) ? slack : 0.0f;                              // also NaN -> 0
         const v4f cnew = { sx, sy, sz, slack };
         certp[i] = cnew;
-        const v2i anew = { __float_as_int(r6), pst | (complete ? 4 : 0) };
+        const v4i anew = { __float_as_int(rn), pst | (complete ? 4 : 0) | (nbr_ok ? 8 : 0), nbr_ok ? nb_n : 0, __float_as_int(fminf(r7, rn)) };
         auxp[i] = anew;
         if (complete && changed) {
 #pragma unroll

@@ -13,6 +13,7 @@ constexpr int kFinThreads = 1024;      // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
 constexpr int kProfWords = 24;         // uint64 words per wave written by the diagnostics variant of k_register
 constexpr int kBlocksQuantum = 8;      // graph cache key granularity (workgroups)
+constexpr int kNbrCap = 16;           // neighbourhood capacity per scan point (s2m_register.hpp: kNbr)
 constexpr int kMaxBlocks = 512;        // largest k_register grid: two 8-wave workgroups on each of the 256 CUs, all co-resident
 
 // Uniform search grid over the map: cell edge E >= sqrt(gate_sq)*(1+2^-10), so the 3x3x3
@@ -55,8 +56,10 @@ struct DevCtx {
     // what a scan point remembers from launch to launch (see s2m_register.hpp); all reset by s2m_set_scan / s2m_set_map
     int32_t* npos;                // [5][n_q] its 5 neighbours, ascending (d2, map index), as positions in map_sorted
     float4*  cert;                // [n_q] {q_ref x,y,z: where the point stood when the tuple was established, slack: how far it may move}
-    int2*    aux;                 // [n_q] {r6 (float bits): no other map point was nearer than this at q_ref, state: bits 0-1 plane 0 none /
-                                  //        1 passed the inlier test / 2 failed it, bit 2 the tuple is complete}
+    int4*    aux;                 // [n_q] {r_out (float bits): every map point outside the neighbourhood was at least this far from q_ref,
+                                  //        state: bits 0-1 plane 0 none / 1 passed the inlier test / 2 failed it, bit 2 the tuple is complete,
+                                  //        bit 3 the neighbourhood is valid, number of neighbourhood members, spare}
+    int32_t* nbr;                 // [kNbr][n_q] the neighbourhood: positions in map_sorted of EVERY map point within r_out of q_ref
     float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to the tuple; pa = NaN: this point contributes nothing
     int32_t n_q, n_m, nblocks;    // nblocks: workgroups of a k_register launch (<= kMaxBlocks; waves loop over the wave table)
     int32_t table_cap;            // capacity of wave_table in entries

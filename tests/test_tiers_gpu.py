@@ -1,0 +1,105 @@
+"""The three ways k_register settles a scan point (liorf_amd/csrc/s2m_register.hpp) must be indistinguishable:
+tier A (certificate: provably unchanged, nothing read), tier B (re-measure the remembered neighbourhood), tier C
+(search: tile, served lanes, fallbacks).  S2M_ABLATE switches tiers and paths off (read at s2m_create): 1 no
+certificates, 2 no re-measuring, 64 no tiles (lanes served one by one), 128 tiles even for a handful of lanes.
+
+  * the surfOptimization() hook against the oracle over walks of poses whose steps span 1e-5 .. 1 m, under every switch
+    (certified lanes report their STORED tuple with distances measured now, so a wrong certificate shows);
+  * the real LM loop: with certificates and re-measuring off every launch searches every point from scratch - its trace
+    has to be BITWISE the trace of the default loop (same tuples -> same planes -> same sums in the same order).
+PARITY UNPINNED beyond the kNN (oracle/s2m_oracle.h).
+"""
+import numpy as np
+import pytest
+
+from liorf_amd import s2m, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SWITCHES = ["0", "1", "2", "3", "64", "128", "130", "67"]
+
+
+def _check(gpu, orc, pose):
+    idx, d2, flag, coeff = gpu.surfOptimization(pose)
+    oidx, od2, oflag, ocoeff = orc.surfOptimization(pose)
+    gated = oidx[:, 0] >= 0
+    assert np.array_equal(idx[:, 0] >= 0, gated), "gate decision differs"
+    assert np.array_equal(idx[gated], oidx[gated]), "neighbour indices differ"
+    assert np.array_equal(d2[gated].view(np.uint32), od2[gated].view(np.uint32)), "neighbour distances differ"
+    assert np.array_equal(flag, oflag) and np.array_equal(coeff.view(np.uint32), ocoeff.view(np.uint32))
+    return int(gated.sum())
+
+
+@pytest.mark.parametrize("ablate", SWITCHES)
+def test_pose_walk_under_every_path(cfg_small, monkeypatch, ablate):
+    monkeypatch.setenv("S2M_ABLATE", ablate)
+    m, s = synth.to_xyzi(cfg_small["map"]), synth.to_xyzi(cfg_small["scan"])
+    gpu = s2m.MapOptimizationS2M()
+    gpu.setInputCloud(m)
+    gpu.setScan(s)
+    orc = O.Oracle(knn_backend=1, num_threads=8)
+    orc.set_map(m)
+    orc.set_scan(s)
+    rng = np.random.default_rng(int(ablate) + 5)
+    p = cfg_small["pose_init"].astype(np.float32)
+    total = 0
+    # a loop-like walk: steps shrinking from 10 cm to 10 um, then a jump, then tiny steps around the new place
+    for scale in (0.0, 0.1, 0.02, 5e-3, 1e-3, 2e-4, 5e-5, 1e-5, 0.0, 1.0, 1e-4, 1e-5, 3e-3):
+        d = rng.normal(0, 1, 6).astype(np.float32) * np.float32(scale) * np.array([0.03, 0.03, 0.03, 1, 1, 1], np.float32)
+        p = (p + d).astype(np.float32)
+        total += _check(gpu, orc, p)
+    assert total > 100000
+    gpu.close()
+    orc.close()
+
+
+def _loop(cfg, ablate, monkeypatch, early_exit):
+    monkeypatch.setenv("S2M_ABLATE", ablate)
+    g = s2m.MapOptimizationS2M(early_exit=early_exit)
+    g.setInputCloud(synth.to_xyzi(cfg["map"]))
+    r = g.optimize(synth.to_xyzi(cfg["scan"]), cfg["pose_init"])
+    tr = g.trace()
+    out = (r.iters_run, r.converged, r.n_sel_last, np.array(r.pose, np.float32),
+           np.array([t.n_sel for t in tr]), np.array([t.pose[:] for t in tr], np.float32), np.array([t.delta[:] for t in tr], np.float32))
+    g.close()
+    return out
+
+
+@pytest.mark.parametrize("name", ["small", "kitti64"])
+def test_loop_with_and_without_certificates_is_bitwise_the_same(name, monkeypatch):
+    cfg = synth.make_config(name)
+    for early_exit in (0, 1):
+        ref = _loop(cfg, "3", monkeypatch, early_exit)            # every launch searches every point
+        for ablate in ("0", "1", "2"):
+            got = _loop(cfg, ablate, monkeypatch, early_exit)
+            assert got[:3] == ref[:3], (ablate, got[:3], ref[:3])
+            assert np.array_equal(got[4], ref[4]), ablate                                       # n_sel per iteration
+            for k in (3, 5, 6):
+                assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (ablate, k)
+    assert ref[0] < 30
+
+
+def test_dense_clump_and_scattered_queries_under_every_path(cfg_small, monkeypatch):
+    """Tile overflow (lanes served / walking their cells), neighbourhoods that do not fit, far points."""
+    rng = np.random.default_rng(11)
+    m = cfg_small["map"]
+    c = m[np.argmax(np.bincount((m[:, 0] // 2).astype(int) - int(m[:, 0].min() // 2)))]
+    q = np.concatenate([(c + rng.normal(0, 1.5, (3000, 3))), (m[rng.choice(len(m), 1500, replace=False)] + rng.normal(0, 0.4, (1500, 3)))]).astype(np.float32)
+    # a very dense patch of the map itself: more than 16 points inside any useful radius
+    dense = (c + rng.normal(0, 0.25, (4000, 3))).astype(np.float32)
+    m2 = np.concatenate([m, dense]).astype(np.float32)
+    for ablate in ("0", "64", "128", "3"):
+        monkeypatch.setenv("S2M_ABLATE", ablate)
+        gpu = s2m.MapOptimizationS2M()
+        gpu.setInputCloud(m2)
+        gpu.setScan(q)
+        orc = O.Oracle(knn_backend=0, num_threads=8)
+        orc.set_map(m2)
+        orc.set_scan(q)
+        p = np.array([0, 0, 0, 0.05, -0.03, 0.02], np.float32)
+        for step in (0.0, 1e-3, 0.05, 1e-5, 0.5, 1e-4):
+            p = (p + np.float32(step)).astype(np.float32)
+            _check(gpu, orc, p)
+        gpu.close()
+        orc.close()
