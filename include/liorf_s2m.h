@@ -148,6 +148,26 @@ int  s2m_optimize_resident(s2m_handle h, float pose[6], const s2m_imu_init* imu,
 int  s2m_optimize_launch(s2m_handle h, const float pose[6]);
 int  s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu,
                           s2m_result* out);
+/* ---- a batch of scans against one resident map (BASELINE config 4 on one GPU; the multi-GPU form shards scans over
+ * ranks, liorf_amd/host/s2m_multi_gpu.cpp) --------------------------------------------------------------------------
+ * The reference registers one scan at a time (laserCloudInfoHandler holds `mtx`, :252); scans of a batch share nothing but the
+ * read-only local map, so n_scans scan2MapOptimization() calls can be in flight at once: every scan
+ * slot has its own buffers, loop state and trace, all slots search the map installed with s2m_set_map / s2m_extract_cloud on
+ * `h`, and the n_scans LM loops run as parallel branches of ONE captured graph (one launch, one synchronisation).  While
+ * one scan's loop waits on the few-microsecond serial chain that closes an LM iteration, the others' points are processed.
+ * Results are those of n_scans separate s2m_optimize calls, bit for bit.
+ *   scans[b], sizes[b]    laserCloudSurfLastDS of scan b (host records, stride_bytes as everywhere)
+ *   poses[6*b .. 6*b+5]   in: initial guess of scan b, out: its transformTobeMapped
+ *   imu                   NULL, or n_scans entries;  out: NULL, or n_scans entries */
+int  s2m_optimize_batch(s2m_handle h, int n_scans, const void* const* scans, const size_t* sizes, size_t stride_bytes,
+                        float* poses, const s2m_imu_init* imu, s2m_result* out);
+/* The same in steps: install scan b in slot b (host or device records; a device source must stay valid until the collect),
+ * enqueue the batch without synchronising, synchronise and fetch. */
+int  s2m_batch_set_scan(s2m_handle h, int slot, const void* pts, size_t n, size_t stride_bytes, int on_device);
+int  s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses);
+int  s2m_optimize_batch_collect(s2m_handle h, int n_scans, float* poses, const s2m_imu_init* imu, s2m_result* out);
+int  s2m_batch_get_trace(s2m_handle h, int slot, s2m_iter_trace* out, int cap);
+
 /* Per-iteration records of the last optimize call; returns the count (<= cap). */
 int  s2m_get_trace(s2m_handle h, s2m_iter_trace* out, int cap);
 

@@ -75,6 +75,18 @@ struct s2m_context {
     int persist_degenerate = 0;
     float persist_matP[36] = { 0 };
 
+    // batch of scans against this handle's map (s2m_optimize_batch): one child context per scan slot.  A child owns its scan-side
+    // buffers, loop state and trace, borrows the parent's map index and runs on the parent's stream; inside the captured batch
+    // graph every child's loop is a branch of its own.
+    s2m_context* parent = nullptr;
+    std::vector<s2m_context*> kids;
+    std::vector<hipStream_t> branch_streams;
+    std::vector<hipEvent_t> branch_events;
+    hipEvent_t ev_fork = nullptr;
+    std::map<std::vector<int>, hipGraphExec_t> batch_graphs;
+    unsigned long long map_epoch = 0;     // bumped by every s2m_set_map: children re-adopt the index when it changed
+    unsigned long long adopted_epoch = 0;
+
     std::map<int, hipGraphExec_t> graphs;
     std::vector<hipEvent_t> iter_events;
     bool use_graph = true;
@@ -176,7 +188,7 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
     if (rc) return rc;
     S2M_HIP(h, hipSetDevice(h->device));
     S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
-    if (n == 0) { h->n_m = 0; h->hctx.n_m = 0; h->ctx_dirty = true; h->t_set_map_ms = 0; return upload_ctx(h); }
+    if (n == 0) { h->map_epoch++; h->n_m = 0; h->hctx.n_m = 0; h->ctx_dirty = true; h->t_set_map_ms = 0; return upload_ctx(h); }
 
     const unsigned char* d_pts;
     if (on_device) d_pts = static_cast<const unsigned char*>(pts);
@@ -233,6 +245,7 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
         S2M_HIP(h, hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream));
         S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int4) * h->n_q, h->stream));
     }
+    h->map_epoch++;
     h->n_m = n;                                       // committed only now: a failure above leaves the old index in place
     h->hctx.n_m = (int32_t)n;
     h->hctx.g = g;
@@ -632,6 +645,12 @@ int s2m_destroy(s2m_handle h)
     if (!h) return S2M_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (s2m_context* k : h->kids) (void)s2m_destroy(k);
+    h->kids.clear();
+    for (auto& kv : h->batch_graphs) (void)hipGraphExecDestroy(kv.second);
+    for (hipStream_t st : h->branch_streams) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : h->branch_events) (void)hipEventDestroy(e);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
@@ -770,6 +789,171 @@ int s2m_optimize(s2m_handle h, const void* scan, size_t n, size_t stride_bytes, 
     int rc = s2m_set_scan(h, scan, n, stride_bytes);
     if (rc) return rc;
     return s2m_optimize_resident(h, pose, imu, out);
+}
+
+// ---- a batch of scans against one resident map -------------------------------------------------------
+namespace {
+
+// child b borrows the parent's map index (no copy) and its per-scan certificates are void when the index changed
+int adopt_map(s2m_context* h, s2m_context* k)
+{
+    if (k->adopted_epoch == h->map_epoch) return S2M_OK;
+    k->n_m = h->n_m;
+    k->hctx.n_m = h->hctx.n_m;
+    k->hctx.g = h->hctx.g;
+    k->hctx.map_sorted = h->hctx.map_sorted;
+    k->hctx.cell_start = h->hctx.cell_start;
+    k->ctx_dirty = true;
+    k->adopted_epoch = h->map_epoch;
+    if (k->have_scan && k->n_q > 0 && k->cert.p) {
+        S2M_HIP(k, hipMemsetAsync(k->cert.p, 0, sizeof(float4) * k->n_q, k->stream));
+        S2M_HIP(k, hipMemsetAsync(k->aux.p, 0, sizeof(int4) * k->n_q, k->stream));
+    }
+    return S2M_OK;
+}
+
+int ensure_kids(s2m_context* h, int n)
+{
+    while ((int)h->kids.size() < n) {
+        s2m_params p = h->prm;
+        p.stream = h->stream;                              // everything outside the captured graph is ordered on the parent's stream
+        s2m_context* k = nullptr;
+        const int rc = s2m_create(&p, &k);
+        if (rc) return fail(h, rc, "batch: could not create a scan slot");
+        k->parent = h;
+        k->hctx.ablate = h->hctx.ablate;
+        h->kids.push_back(k);
+        hipStream_t st = nullptr;
+        hipEvent_t ev = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            return fail(h, S2M_ERR_HIP, "batch: stream / event creation failed");
+        h->branch_streams.push_back(st);
+        h->branch_events.push_back(ev);
+    }
+    if (!h->ev_fork && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, S2M_ERR_HIP, "batch: event creation failed");
+    return S2M_OK;
+}
+
+// One graph for the whole batch: a fork, one branch per scan with that scan's loop (enqueue_loop), a join.
+int get_batch_graph(s2m_context* h, const std::vector<int>& live, hipGraphExec_t* out)
+{
+    std::vector<int> key;
+    for (int b : live) { key.push_back(b); key.push_back(h->kids[(size_t)b]->hctx.table_cap); }
+    auto it = h->batch_graphs.find(key);
+    if (it != h->batch_graphs.end()) { *out = it->second; return S2M_OK; }
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    S2M_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    bool ok = hipEventRecord(h->ev_fork, h->stream) == hipSuccess;
+    for (int b : live) {
+        s2m_context* k = h->kids[(size_t)b];
+        hipStream_t br = h->branch_streams[(size_t)b];
+        ok = ok && hipStreamWaitEvent(br, h->ev_fork, 0) == hipSuccess;
+        k->stream = br;
+        enqueue_loop(k, k->hctx.nblocks, k->dctx.as<DevCtx>(), nullptr);
+        k->stream = h->stream;
+        ok = ok && hipEventRecord(h->branch_events[(size_t)b], br) == hipSuccess;
+        ok = ok && hipStreamWaitEvent(h->stream, h->branch_events[(size_t)b], 0) == hipSuccess;
+    }
+    hipError_t e = hipStreamEndCapture(h->stream, &graph);
+    if (!ok || e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "batch: stream capture failed", e);
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(h, S2M_ERR_HIP, "batch: hipGraphInstantiate", e);
+    h->batch_graphs[key] = exec;
+    *out = exec;
+    return S2M_OK;
+}
+
+}  // namespace
+
+int s2m_batch_set_scan(s2m_handle h, int slot, const void* pts, size_t n, size_t stride_bytes, int on_device)
+{
+    if (!h || slot < 0 || slot >= 64) return S2M_ERR_INVALID_ARG;
+    S2M_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_kids(h, slot + 1);
+    if (rc) return rc;
+    s2m_context* k = h->kids[(size_t)slot];
+    if ((rc = adopt_map(h, k))) return fail(h, rc, k->err.c_str());
+    if ((rc = set_scan_impl(k, pts, n, stride_bytes, on_device != 0))) return fail(h, rc, k->err.c_str());
+    return S2M_OK;
+}
+
+int s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses)
+{
+    if (!h || n_scans < 1 || n_scans > 64 || !poses) return S2M_ERR_INVALID_ARG;
+    if ((int)h->kids.size() < n_scans) return fail(h, S2M_ERR_NO_SCAN, "s2m_batch_set_scan has not been called for every slot");
+    S2M_HIP(h, hipSetDevice(h->device));
+    std::vector<int> live;
+    int rc;
+    for (int b = 0; b < n_scans; b++) {
+        s2m_context* k = h->kids[(size_t)b];
+        if (!k->have_scan) return fail(h, S2M_ERR_NO_SCAN, "s2m_batch_set_scan has not been called for every slot");
+        if (k->prm.early_exit != h->prm.early_exit || k->prm.max_iter != h->prm.max_iter || memcmp(&k->prm.gate_sq, &h->prm.gate_sq, sizeof(double)) != 0) {
+            s2m_params p = h->prm;                         // parameters changed on the parent since the slot was made
+            p.stream = k->prm.stream;
+            if ((rc = s2m_set_params(k, &p))) return fail(h, rc, k->err.c_str());
+        } else {
+            k->prm.z_tol = h->prm.z_tol; k->prm.rot_tol = h->prm.rot_tol; k->prm.imu_type = h->prm.imu_type; k->prm.imu_rpy_weight = h->prm.imu_rpy_weight;
+        }
+        if ((rc = adopt_map(h, k))) return fail(h, rc, k->err.c_str());
+        memcpy(k->pending_pose_in, poses + 6 * (size_t)b, 24);
+        k->opt_pending = true;
+        k->pending_skipped = 0;
+        if (k->n_m == 0) { k->pending_skipped = 1; continue; }                            // :1297
+        if ((int)k->n_q <= k->prm.min_feats) { k->pending_skipped = 2; continue; }         // :1300
+        if ((rc = upload_ctx(k))) return fail(h, rc, k->err.c_str());
+        if ((rc = push_state(k, poses + 6 * (size_t)b))) return fail(h, rc, k->err.c_str());
+        live.push_back(b);
+    }
+    S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
+    if (!live.empty()) {
+        hipGraphExec_t exec = nullptr;
+        if ((rc = get_batch_graph(h, live, &exec))) return rc;
+        S2M_HIP(h, hipGraphLaunch(exec, h->stream));
+    }
+    S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    for (int b : live) {
+        s2m_context* k = h->kids[(size_t)b];
+        k->hctx.density_pending = 0;
+        S2M_HIP(h, hipEventRecord(k->ev_a, h->stream)); S2M_HIP(h, hipEventRecord(k->ev_b, h->stream));     // (collect reads a per-handle time)
+        S2M_HIP(h, hipMemcpyAsync(&k->h_state[1], k->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
+        S2M_HIP(h, hipMemcpyAsync(k->h_trace, k->trace.p, sizeof(s2m_iter_trace) * k->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
+    }
+    return S2M_OK;
+}
+
+int s2m_optimize_batch_collect(s2m_handle h, int n_scans, float* poses, const s2m_imu_init* imu, s2m_result* out)
+{
+    if (!h || n_scans < 1 || (int)h->kids.size() < n_scans || !poses) return S2M_ERR_INVALID_ARG;
+    S2M_HIP(h, hipSetDevice(h->device));
+    S2M_HIP(h, hipStreamSynchronize(h->stream));
+    S2M_HIP(h, hipEventElapsedTime(&h->t_optimize_ms, h->ev_a, h->ev_b));
+    for (int b = 0; b < n_scans; b++) {
+        s2m_context* k = h->kids[(size_t)b];
+        const int rc = s2m_optimize_collect(k, poses + 6 * (size_t)b, imu ? imu + b : nullptr, out ? out + b : nullptr);
+        if (rc) return fail(h, rc, k->err.c_str());
+    }
+    return S2M_OK;
+}
+
+int s2m_optimize_batch(s2m_handle h, int n_scans, const void* const* scans, const size_t* sizes, size_t stride_bytes,
+                       float* poses, const s2m_imu_init* imu, s2m_result* out)
+{
+    if (!h || n_scans < 1 || n_scans > 64 || !scans || !sizes || !poses) return S2M_ERR_INVALID_ARG;
+    for (int b = 0; b < n_scans; b++) {
+        const int rc = s2m_batch_set_scan(h, b, scans[b], sizes[b], stride_bytes, 0);
+        if (rc) return rc;
+    }
+    const int rc = s2m_optimize_batch_launch(h, n_scans, poses);
+    if (rc) return rc;
+    return s2m_optimize_batch_collect(h, n_scans, poses, imu, out);
+}
+
+int s2m_batch_get_trace(s2m_handle h, int slot, s2m_iter_trace* out, int cap)
+{
+    if (!h || slot < 0 || slot >= (int)h->kids.size()) return S2M_ERR_INVALID_ARG;
+    return s2m_get_trace(h->kids[(size_t)slot], out, cap);
 }
 
 int s2m_get_trace(s2m_handle h, s2m_iter_trace* out, int cap)

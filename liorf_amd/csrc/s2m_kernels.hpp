@@ -742,7 +742,7 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // shared constants and wave-level helpers of the registration kernel (s2m_register.hpp)
 // ------------------------------------------------------------------------------------------
 constexpr int kTilePts = 320;        // points per wave tile (5 KiB) after filtering
-constexpr int kTileRaw = 448;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
+constexpr int kTileRaw = 640;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
 constexpr int kCand = 24;            // candidate-list capacity per lane (tile positions, uint16)
 constexpr int kRowMax = 256;         // boxes with more rows go straight to the gather path
 constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning (<= 5e-5)

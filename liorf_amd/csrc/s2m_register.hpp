@@ -57,7 +57,7 @@
 constexpr float kCertMargin = 2e-6f;   // metres; see tier A above
 constexpr float kNbrReach   = 0.15f;   // metres beyond the 5th neighbour that a search tries to cover with the neighbourhood ...
 constexpr float kNbrReachCold = 0.10f; // ... and beyond the gate when it has no tuple to start from (first launch of a scan)
-constexpr int   kWalkLanes = 16;       // a wave whose tile overflowed serves up to this many lanes one by one; beyond, every lane walks its own cells
+constexpr int   kWalkLanes = 64;       // a wave whose tile overflowed serves up to this many lanes one by one; beyond, every lane walks its own cells
 constexpr int   kNbr = kNbrCap;        // neighbourhood capacity (map positions per scan point)
 constexpr int   kLevels = 6;           // radii a search counts against at once
 constexpr int   kServeLanes = 8;       // up to this many searching lanes are served one by one instead of staging a tile
@@ -251,10 +251,11 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             Top6k t;
 #pragma unroll
             for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
-            uint64_t k7 = kKeyInf;                         // the nearest of the members stored behind the first six
+            uint64_t k7 = kKeyInf;                         // the nearest member outside the six nearest
             bool open = ev;                                // lanes not settled yet
+            int np6[6];                                    // the six members in front
             {
-                int np_[6];
+                int (&np_)[6] = np6;
 #pragma unroll
                 for (int k = 0; k < 6; k++) { np_[k] = 0; if (ev && k < nb_n) np_[k] = nbrp[(size_t)k * nq + i]; }
                 v3f mm[6];
@@ -294,8 +295,37 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                         const float dx = sx - mm[k - 6].x, dy = sy - mm[k - 6].y, dz = sz - mm[k - 6].z;
                         const float d2 = (dx * dx + dy * dy) + dz * dz;
                         const uint64_t key = on ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)np_[k - 6]) : kKeyInf;
-                        k7 = (key < k7) ? key : k7;          // nearest of the members behind the six in front
-                        if (__ballot(key < t.key[5])) top6k_insert(t, key);
+                        if (__ballot(key < t.key[5])) { const uint64_t out = top6k_insert(t, key); k7 = (out < k7) ? out : k7; }
+                        else k7 = (key < k7) ? key : k7;     // the smallest key left outside the six: the 7th nearest
+                    }
+                }
+                // If a member from behind made it into the six nearest, the stored list is put in order again (the six nearest in
+                // front, the rest behind): the early out above and the 7th-nearest bound rely on that order.
+                bool moved = false;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    bool infront = key_hi(t.key[q]) >= 0x7f800000u;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) infront = infront || ((int)key_lo(t.key[q]) == np6[k] && k < nb_n);
+                    moved = moved || !infront;
+                }
+                moved = moved && open;
+                if (__ballot(moved)) {
+                    int slot = 0;
+                    if (moved) {
+#pragma unroll
+                        for (int q = 0; q < 6; q++)
+                            if (key_hi(t.key[q]) < 0x7f800000u) { nbrp[(size_t)slot * nq + i] = (int)key_lo(t.key[q]); slot++; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < kNbr; k++) {
+                        if (k < nmax) {
+                            const int pk = (k < 6) ? np6[k < 6 ? k : 0] : np_[k >= 6 ? k - 6 : 0];
+                            bool in6 = false;
+#pragma unroll
+                            for (int q = 0; q < 6; q++) in6 = in6 || (key_hi(t.key[q]) < 0x7f800000u && pk == (int)key_lo(t.key[q]));
+                            if (moved && k < nb_n && !in6 && slot < kNbr) { nbrp[(size_t)slot * nq + i] = pk; slot++; }
+                        }
                     }
                 }
             }
@@ -308,8 +338,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 #pragma unroll
                     for (int q = 0; q < 6; q++) top.key[q] = t.key[q];
                     rn = r; settled = true;
-                    // r7 keeps describing the six members IN FRONT of the stored list (whichever six are nearest now): everything
-                    // else is the other members, measured just now, and the outside
+                    // the stored list has the six nearest in front again: everything else is the 7th nearest member and beyond
                     r7 = (key_hi(k7) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(k7))) * 0.999999f, r) : r;
                 }
             }
@@ -470,53 +499,95 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 for (int k = 0; k < kLevels; k++) tl[k] = fminf(gatef * fr[k], be2);
                 tl[0] = be2;
             }
+            // A wave of a split chunk holds 32, 16 or 8 points in its first lanes (they sit in dense parts of the map and
+            // have the biggest tiles); when all of them search, the idle lanes join in: kq = 2, 4 or 8 lanes share a point,
+            // each sweeps every kq-th tile point, and the results are combined across the group.
+            const bool packed = cmask == ((chunk.y >= 64) ? ~0ull : ((1ull << chunk.y) - 1ull));
+            const int kq = !packed ? 1 : ((chunk.y > 32) ? 1 : ((chunk.y > 16) ? 2 : ((chunk.y > 8) ? 4 : 8)));
+            const int nslot = 64 / kq, part = lane / nslot;
+            float qx_ = sx, qy_ = sy, qz_ = sz;
+            float ql_[kLevels];
+#pragma unroll
+            for (int k = 0; k < kLevels; k++) ql_[k] = tl[k];
+            if (kq > 1) {
+                const int src = lane & (nslot - 1);
+                qx_ = __shfl(sx, src, 64); qy_ = __shfl(sy, src, 64); qz_ = __shfl(sz, src, 64);
+#pragma unroll
+                for (int k = 0; k < kLevels; k++) ql_[k] = __shfl(tl[k], src, 64);
+            }
             // ---- count the tile points inside the kLevels radii of every searching lane (branch-free)
             int c[kLevels];
 #pragma unroll
             for (int k = 0; k < kLevels; k++) c[k] = 0;
             {
-                int j = 0;
-                for (; j + 2 <= nt; j += 2) {                 // two LDS reads in flight
-                    const v4f m0 = lpts[j], m1 = lpts[j + 1];
+                int j = part;
+                for (; j + kq < nt; j += 2 * kq) {            // two LDS reads in flight
+                    const v4f m0 = lpts[j], m1 = lpts[j + kq];
                     float d0, d1;
-                    make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                    make_key(m0, qx_, qy_, qz_, d0); make_key(m1, qx_, qy_, qz_, d1);
 #pragma unroll
-                    for (int k = 0; k < kLevels; k++) c[k] += ((d0 <= tl[k]) ? 1 : 0) + ((d1 <= tl[k]) ? 1 : 0);
+                    for (int k = 0; k < kLevels; k++) c[k] += ((d0 <= ql_[k]) ? 1 : 0) + ((d1 <= ql_[k]) ? 1 : 0);
                 }
-                for (; j < nt; j++) {
-                    float d; make_key(lpts[j], sx, sy, sz, d);
+                for (; j < nt; j += kq) {
+                    float d; make_key(lpts[j], qx_, qy_, qz_, d);
 #pragma unroll
-                    for (int k = 0; k < kLevels; k++) c[k] += (d <= tl[k]) ? 1 : 0;
+                    for (int k = 0; k < kLevels; k++) c[k] += (d <= ql_[k]) ? 1 : 0;
                 }
+            }
+            for (int m = nslot; m < 64; m <<= 1) {
+#pragma unroll
+                for (int k = 0; k < kLevels; k++) c[k] += __shfl_xor(c[k], m, 64);
             }
             // the widest level that fits; it has to hold the tuple (5 points) unless even the gate holds fewer than 5
             // (a tuple to start from whose 5th member is beyond the gate has bound = gate: the last level counts the gate)
             int cl = c[kLevels - 1];
-            float lvl2 = tl[kLevels - 1];
+            float lvl2 = ql_[kLevels - 1];
 #pragma unroll
-            for (int k = kLevels - 2; k >= 0; k--) { const bool fits = c[k] <= kNbr; lvl2 = fits ? tl[k] : lvl2; cl = fits ? c[k] : cl; }
-            const int c_gate = has_prior ? c[kLevels - 1] : c[1];
-            const bool fallback = searching && (cl > kNbr || (cl < 5 && c_gate >= 5));
-            // ---- the neighbourhood: tile slots inside the level, written down in a second branch-free sweep
+            for (int k = kLevels - 2; k >= 0; k--) { const bool fits = c[k] <= kNbr; lvl2 = fits ? ql_[k] : lvl2; cl = fits ? c[k] : cl; }
+            const bool q_prior = (kq > 1) ? (__shfl((int)has_prior, lane & (nslot - 1), 64) != 0) : has_prior;
+            const bool q_search = (kq > 1) ? (__shfl((int)searching, lane & (nslot - 1), 64) != 0) : searching;
+            const int c_gate = q_prior ? c[kLevels - 1] : c[1];
+            const bool q_fallback = q_search && (cl > kNbr || (cl < 5 && c_gate >= 5));
+            const bool fallback = searching && q_fallback;                 // (owner lanes: part 0 of their group)
+            // ---- the neighbourhood: tile slots inside the level, written down in a second branch-free sweep; the nearest
+            // tile point beyond the level tells how far the neighbourhood really reaches
             const bool lister = searching && !fallback;
             int cc = 0;
-            if (lister) {
-                int j = 0;
-                for (; j + 4 <= nt; j += 4) {                 // four LDS reads in flight
-                    const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
+            float mo = INFINITY;
+            if (q_search && !q_fallback) {
+                int j = part;
+                for (; j + 3 * kq < nt; j += 4 * kq) {        // four LDS reads in flight
+                    const v4f m0 = lpts[j], m1 = lpts[j + kq], m2 = lpts[j + 2 * kq], m3 = lpts[j + 3 * kq];
                     float d0, d1, d2v, d3;
-                    make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                    make_key(m2, sx, sy, sz, d2v); make_key(m3, sx, sy, sz, d3);
+                    make_key(m0, qx_, qy_, qz_, d0); make_key(m1, qx_, qy_, qz_, d1);
+                    make_key(m2, qx_, qy_, qz_, d2v); make_key(m3, qx_, qy_, qz_, d3);
                     if (d0 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
-                    if (d1 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 1); cc++; }
-                    if (d2v <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 2); cc++; }
-                    if (d3 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 3); cc++; }
+                    if (d1 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + kq); cc++; }
+                    if (d2v <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 2 * kq); cc++; }
+                    if (d3 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 3 * kq); cc++; }
+                    mo = fminf(fminf(mo, (d0 > lvl2) ? d0 : INFINITY), (d1 > lvl2) ? d1 : INFINITY);
+                    mo = fminf(fminf(mo, (d2v > lvl2) ? d2v : INFINITY), (d3 > lvl2) ? d3 : INFINITY);
                 }
-                for (; j < nt; j++) {
-                    float d; make_key(lpts[j], sx, sy, sz, d);
+                for (; j < nt; j += kq) {
+                    float d; make_key(lpts[j], qx_, qy_, qz_, d);
                     if (d <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
+                    mo = fminf(mo, (d > lvl2) ? d : INFINITY);
                 }
             }
+            if (kq > 1) {
+                // the group's lists go into the owner's column
+                wave_lds_sync();
+                for (int m = nslot; m < 64; m <<= 1) mo = fminf(mo, __shfl_xor(mo, m, 64));
+                int tot = cc;
+                for (int pp = 1; pp < kq; pp++) {
+                    const int n_pp = __shfl(cc, (lane & (nslot - 1)) + pp * nslot, 64);
+                    if (part == 0 && lister) {
+                        for (int k = 0; k < n_pp && tot < kNbr; k++) { lcand[tot * 64 + lane] = lcand[k * 64 + lane + pp * nslot]; tot++; }
+                    }
+                }
+                cc = (part == 0) ? tot : 0;
+            }
+            if (!lister) cc = 0;
             wave_lds_sync();
             // ---- its six nearest (the lanes insert their k-th member together), then the neighbourhood goes to memory with
             // those six in front
@@ -538,7 +609,9 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 if (lister) {
 #pragma unroll
                     for (int k = 0; k < 6; k++) top.key[k] = t.key[k];
-                    nb_n = cc; rn = sqrtf(lvl2) * 0.999999f; nbr_ok = true; settled = true;
+                    // every tile point within the level is a member, the nearest beyond it is `mo` away, and beyond the reach
+                    // nothing is known
+                    nb_n = cc; rn = sqrtf((cp->ablate & 256) ? lvl2 : fminf(fmaxf(mo, lvl2), be * be)) * 0.999999f; nbr_ok = true; settled = true;
                     r7 = (key_hi(k7) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(k7))), rn) : rn;
                     int slot = 0;
 #pragma unroll

@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "s2m_version", "s2m_default_params", "s2m_create", "s2m_destroy", "s2m_last_error", "s2m_set_params", "s2m_get_params",
     "s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device",
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
+    "s2m_optimize_batch", "s2m_batch_set_scan", "s2m_optimize_batch_launch", "s2m_optimize_batch_collect", "s2m_batch_get_trace",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
     "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile", "s2m_debug_time_steady",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
@@ -130,6 +131,11 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_optimize_launch.argtypes = [vp, fp]
     L.s2m_optimize_collect.argtypes = [vp, fp, C.POINTER(ImuInit), C.POINTER(Result)]
     L.s2m_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
+    L.s2m_optimize_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, fp, C.POINTER(ImuInit), C.POINTER(Result)]
+    L.s2m_batch_set_scan.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.s2m_optimize_batch_launch.argtypes = [vp, C.c_int, fp]
+    L.s2m_optimize_batch_collect.argtypes = [vp, C.c_int, fp, C.POINTER(ImuInit), C.POINTER(Result)]
+    L.s2m_batch_get_trace.argtypes = [vp, C.c_int, C.POINTER(IterTrace), C.c_int]
     L.s2m_surf_optimization.argtypes = [vp, fp, C.POINTER(C.c_int32), fp, C.POINTER(C.c_uint8), fp]
     L.s2m_normal_eq.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_int32)]
     L.s2m_last_timing.argtypes = [vp, fp, fp, fp]
@@ -361,6 +367,52 @@ class MapOptimizationS2M:
         self.isDegenerate = bool(r.is_degenerate)
         self.last_result = r
         return r
+
+    # -- a batch of scans against the resident map (BASELINE config 4 on one GPU) ---------------------
+    def batchSetScan(self, slot: int, scan=None, device_ptr=None):
+        """Install scan `slot` of the batch: host records, or device_ptr=(ptr, n, stride_bytes)."""
+        if device_ptr is not None:
+            ptr, n, st = device_ptr
+            self._check(self.lib.s2m_batch_set_scan(self.h, slot, C.c_void_p(ptr), n, st, 1), "s2m_batch_set_scan")
+        else:
+            a, n, st = _records(scan)
+            self._check(self.lib.s2m_batch_set_scan(self.h, slot, a.ctypes.data, n, st, 0), "s2m_batch_set_scan")
+
+    def batchLaunch(self, poses):
+        p = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)
+        self._batch_n = p.shape[0]
+        self._check(self.lib.s2m_optimize_batch_launch(self.h, p.shape[0], _fp(p)), "s2m_optimize_batch_launch")
+
+    def batchCollect(self, imus=None):
+        n = self._batch_n
+        poses = np.zeros((n, 6), np.float32)
+        res = (Result * n)()
+        im = None
+        if imus is not None:
+            im = (ImuInit * n)(*imus)
+        self._check(self.lib.s2m_optimize_batch_collect(self.h, n, _fp(poses), im, res), "s2m_optimize_batch_collect")
+        return poses, [res[k] for k in range(n)]
+
+    def optimizeBatch(self, scans, poses, imus=None):
+        """s2m_optimize_batch: n scan2MapOptimization() calls against the resident map in one graph; (poses, results)."""
+        keep = [_records(sc) for sc in scans]
+        n = len(keep)
+        st = keep[0][2]
+        if any(k[2] != st for k in keep):
+            raise ValueError("all scans of a batch must share one record stride")
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(k[0].ctypes.data) for k in keep])
+        sizes = (C.c_size_t * n)(*[k[1] for k in keep])
+        p = np.ascontiguousarray(poses, np.float32).reshape(n, 6).copy()
+        res = (Result * n)()
+        im = (ImuInit * n)(*imus) if imus is not None else None
+        self._check(self.lib.s2m_optimize_batch(self.h, n, ptrs, sizes, st, _fp(p), im, res), "s2m_optimize_batch")
+        self._batch_n = n
+        return p, [res[k] for k in range(n)]
+
+    def batchTrace(self, slot: int) -> list[IterTrace]:
+        buf = (IterTrace * 64)()
+        n = self.lib.s2m_batch_get_trace(self.h, slot, buf, 64)
+        return [buf[i] for i in range(max(n, 0))]
 
     def trace(self) -> list[IterTrace]:
         buf = (IterTrace * 64)()

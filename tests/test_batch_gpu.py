@@ -1,0 +1,93 @@
+"""s2m_optimize_batch: n scan2MapOptimization() calls against one resident map as parallel branches of one captured
+graph (BASELINE config 4 on a single GPU).  Bar: every scan's result, trace and transformUpdate() output are BITWISE
+those of a separate s2m_optimize call on a handle of its own; soft conditions (:1297, :1300) per slot; slots are
+reusable across batches, batch sizes and maps.  The oracle checks one batch end to end."""
+import numpy as np
+import pytest
+
+from liorf_amd import s2m, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _solo(m, scan, pose, imu=None, **kw):
+    g = s2m.MapOptimizationS2M(**kw)
+    g.setInputCloud(m)
+    r = g.optimize(scan, pose, imu=imu)
+    tr = np.array([t.pose[:] for t in g.trace()], np.float32)
+    g.close()
+    return np.array(r.pose, np.float32), (r.iters_run, r.converged, r.is_degenerate, r.n_sel_last, r.skipped), np.array(r.affine, np.float32), tr
+
+
+def test_batch_equals_separate_calls_bitwise():
+    cfgs = [synth.make_config("small", scan_index=k) for k in range(5)]
+    m = synth.to_xyzi(cfgs[0]["map"])
+    scans = [synth.to_xyzi(c["scan"]) for c in cfgs]
+    scans[3] = scans[3][:7001]                                   # ragged sizes
+    scans[4] = scans[4][:30]                                     # not enough features (:1300): skipped, pose untouched
+    poses = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
+    solo = [_solo(m, s, p) for s, p in zip(scans, poses)]
+    gpu = s2m.MapOptimizationS2M()
+    gpu.setInputCloud(m)
+    for rep in range(2):                                          # second batch: slots, graph and buffers re-used
+        out, res = gpu.optimizeBatch(scans, poses)
+        for b in range(5):
+            assert (res[b].iters_run, res[b].converged, res[b].is_degenerate, res[b].n_sel_last, res[b].skipped) == solo[b][1], b
+            assert np.array_equal(out[b].view(np.uint32), solo[b][0].view(np.uint32)), b
+            assert np.array_equal(np.array(res[b].affine, np.float32).view(np.uint32), solo[b][2].view(np.uint32)), b
+            tr = np.array([t.pose[:] for t in gpu.batchTrace(b)], np.float32)
+            assert tr.shape == solo[b][3].shape and np.array_equal(tr.view(np.uint32), solo[b][3].view(np.uint32)), b
+    assert res[4].skipped == 2 and np.array_equal(out[4], poses[4])
+    # a smaller batch on the same handle, then the single-scan entry point of the parent: both unaffected by the slots
+    out, res = gpu.optimizeBatch(scans[:2], poses[:2])
+    for b in range(2):
+        assert np.array_equal(out[b].view(np.uint32), solo[b][0].view(np.uint32))
+    r = gpu.optimize(scans[1], poses[1])
+    assert np.array_equal(np.array(r.pose, np.float32).view(np.uint32), solo[1][0].view(np.uint32))
+    # against the oracle, one scan of the batch
+    orc = O.Oracle(knn_backend=1, num_threads=8)
+    orc.set_map(m)
+    orc.set_scan(scans[2])
+    ro = orc.scan2MapOptimization(poses[2])
+    assert ro.iters_run == solo[2][1][0] and np.abs(np.array(ro.pose) - solo[2][0]).max() <= 1e-5
+    gpu.close()
+
+
+def test_batch_follows_map_and_parameter_changes(cfg_tiny, cfg_small):
+    gpu = s2m.MapOptimizationS2M()
+    for cfg in (cfg_small, cfg_tiny, cfg_small):                   # the map under the slots changes: certificates must not leak
+        m, s = synth.to_xyzi(cfg["map"]), synth.to_xyzi(cfg["scan"])
+        gpu.setInputCloud(m)
+        p = np.stack([cfg["pose_init"], cfg["pose_init"] + np.float32(0.01)]).astype(np.float32)
+        out, res = gpu.optimizeBatch([s, s], p)
+        for b in range(2):
+            want = _solo(m, s, p[b])
+            assert np.array_equal(out[b].view(np.uint32), want[0].view(np.uint32)), b
+    # parameters set on the handle after the slots exist reach them (transformUpdate clamps, early exit)
+    m, s = synth.to_xyzi(cfg_small["map"]), synth.to_xyzi(cfg_small["scan"])
+    gpu.setParams(z_tol=0.05, rot_tol=0.005, early_exit=0)
+    p = np.stack([cfg_small["pose_init"]] * 2).astype(np.float32)
+    out, res = gpu.optimizeBatch([s, s], p)
+    want = _solo(m, s, p[0], z_tol=0.05, rot_tol=0.005, early_exit=0)
+    assert res[0].iters_run == 30 and abs(out[0][5]) <= np.float32(0.05) and abs(out[0][0]) <= np.float32(0.005)
+    assert np.array_equal(out[0].view(np.uint32), want[0].view(np.uint32)) and np.array_equal(out[1], out[0])
+    gpu.close()
+
+
+def test_batch_of_eight_kitti64_scans(cfg_kitti64):
+    """BASELINE config 4's batch (8 scans from 8 seeded poses along a path, one map) on one GPU."""
+    m = synth.to_xyzi(cfg_kitti64["map"])
+    cfgs = [cfg_kitti64] + [synth.make_config("kitti64", scan_index=k) for k in range(1, 8)]
+    scans = [synth.to_xyzi(c["scan"]) for c in cfgs]
+    poses = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
+    gpu = s2m.MapOptimizationS2M()
+    gpu.setInputCloud(m)
+    out, res = gpu.optimizeBatch(scans, poses)
+    for b in (0, 3, 7):
+        want = _solo(m, scans[b], poses[b])
+        assert np.array_equal(out[b].view(np.uint32), want[0].view(np.uint32)), b
+    for b in range(8):
+        assert res[b].converged == 1 and res[b].iters_run < 30
+        assert np.abs(out[b][3:] - cfgs[b]["pose_gt"][3:]).max() < 0.03
+    gpu.close()
