@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--cpu-scans", type=int, default=10)
+    ap.add_argument("--batch", action="store_true", help="also time 2 and 4 scans in flight against one map (s2m_optimize_batch)")
     args = ap.parse_args()
 
     import torch
@@ -134,22 +135,77 @@ def main():
         dt = float(tt.item())
     ms_per_step = 1e3 * dt / args.steps
     value = world * args.steps * max_iter / dt            # whole-job LM iterations / s
+    # four more windows of the same K steps, for the spread of the figure above (not part of `value`)
+    windows = [ms_per_step]
+    for _ in range(4):
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            r = step()
+        fence()
+        windows.append(1e3 * (time.perf_counter() - t1) / args.steps)
 
     # ---- dominant kernel, timed live with HIP events on the library's stream ------------------
     per_iter_ms = eng.time_iterations(cfg["pose_init"], reps=10)       # 10 loops x 30 launches, event pair per launch
     kernel_ms = float(per_iter_ms.mean())
     b_alg = 12.0 * (n_q + n_m)                             # SoA fp32 xyz read once
     achieved = b_alg / (kernel_ms * 1e-3)
-    # HBM-side bytes per launch from the committed PMC passes (profiles/, same workload): FETCH_SIZE is
-    # doubled (the gfx950 correction for 16-B-per-lane reads, MI355X_MICROARCH.md), WRITE_SIZE as is
+    # HBM-side bytes per launch from the committed PMC passes of this workload (profiles/): FETCH_SIZE is doubled (the gfx950
+    # correction for 16-B-per-lane reads, MI355X_MICROARCH.md), WRITE_SIZE as is.  The counters need rocprofv3 and cannot be
+    # taken inside this run; they are reported only if they were taken on the kernel sources that are running (the file is
+    # stamped with a hash of liorf_amd/csrc), otherwise traffic is null and traffic_stale says why.
     traffic = traffic_raw = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_k_register_pmc.json")
-    if args.workload == "kitti64" and os.path.exists(pmc_file):
+    traffic_stale = None
+    pmc_file = os.path.join(ROOT, "profiles", f"r02_k_register_pmc_{args.workload}.json")
+    if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
-        f_kb, w_kb = pmc["FETCH_SIZE"]["mean_KB"], pmc["WRITE_SIZE"]["mean_KB"]
-        traffic_raw = round((f_kb + w_kb) * 1024.0)
-        traffic = round((2.0 * f_kb + w_kb) * 1024.0)
+        if pmc.get("kernel_source_sha") == s2m.kernel_source_sha():
+            f_kb, w_kb = pmc["FETCH_SIZE"]["mean_KB"], pmc["WRITE_SIZE"]["mean_KB"]
+            traffic_raw = round((f_kb + w_kb) * 1024.0)
+            traffic = round((2.0 * f_kb + w_kb) * 1024.0)
+            traffic_stale = False
+        else:
+            traffic_stale = True
     device_ms = eng.timing()["optimize_ms"]
+
+    # ---- what the reference actually does: break when LMOptimization() returns true (:1313) -----------------------
+    early = {}
+    if world == 1:
+        e2 = s2m.MapOptimizationS2M(device_id=local_rank, early_exit=1)
+        e2.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
+        ts = []
+        for k in range(13):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            e2.setScanDevice(d_scan.data_ptr(), n_q, 32)
+            e2.launch(cfg["pose_init"])
+            r2 = e2.collect()
+            ts.append(time.perf_counter() - t1)
+        early = {"ms_per_scan_early_exit": round(1e3 * float(np.median(ts[3:])), 4), "iters_run_early_exit": r2.iters_run,
+                 "device_ms_early_exit": round(e2.timing()["optimize_ms"], 4)}
+        # ---- several scans against the same map in one graph (BASELINE config 4 on one GPU) ---------------------------
+        batch_out = []
+        if args.batch:
+            d_more = [d_scan] + [torch.from_numpy(synth.to_xyzi(synth.make_config(args.workload, scan_index=k)["scan"])).to(dev) for k in range(1, 4)]
+            p_more = np.stack([cfg["pose_init"]] + [synth.make_config(args.workload, scan_index=k)["pose_init"] for k in range(1, 4)]).astype(np.float32)
+            for B in (2, 4):
+                def bstep():
+                    for b in range(B):
+                        eng.batchSetScan(b, device_ptr=(d_more[b].data_ptr(), int(d_more[b].shape[0]), 32))
+                    eng.batchLaunch(p_more[:B])
+                    return eng.batchCollect()
+                for _ in range(2):
+                    bstep()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    _, bres = bstep()
+                torch.cuda.synchronize()
+                tb = (time.perf_counter() - t1) / 10
+                batch_out.append({"scans_in_flight": B, "ms_per_batch": round(1e3 * tb, 4),
+                                  "lm_iterations_per_s": round(sum(x.iters_run for x in bres) / tb, 1)})
+        early["batch_one_gpu"] = batch_out
+        e2.close()
 
     out = {
         "metric": "LM iterations/sec (64-line scan vs 200k-pt map)",
@@ -173,12 +229,16 @@ def main():
         "roofline": {
             "bound": "hbm", "kernel": "k_register",
             "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw,
-            "traffic_source": "profiles/r01_k_register_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+            "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw, "traffic_stale": traffic_stale,
+            "traffic_source": f"profiles/r02_k_register_pmc_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                              "stamped with the hash of the kernel sources it was taken on)",
             "algorithmic_bytes_per_launch": b_alg, "kernel_us": round(kernel_ms * 1e3, 3),
             "frac_of_measured_achievable": round(achieved / HBM_ACHIEVABLE, 5),
         },
+        "ms_per_step_windows": {"min": round(min(windows), 4), "median": round(float(np.median(windows)), 4), "max": round(max(windows), 4), "n": len(windows)},
         "kernel_us_by_iteration": [round(float(v) * 1e3, 1) for v in per_iter_ms],
+        "kernel_us_steady_back_to_back": round(eng.time_steady(cfg["pose_init"], 200, True), 2),
+        **early,
         "knn_mpts_per_s": round(n_q / (kernel_ms * 1e-3) / 1e6, 1),
         "device_ms_per_step": round(device_ms, 4),
         "map_index_build_ms": round(tm["set_map_ms"], 4),

@@ -1030,12 +1030,15 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
         T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = pose[5];
         sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
     }
+    // wave-uniform by construction: into scalar registers, out of the way of everything below
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(T[k])));
+#pragma unroll
+    for (int k = 0; k < 6; k++) sc6[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sc6[k])));
     if (HOOK) lm_stamps[6] = wall_clock64();
 
     WaveProf prof;
-    double acc[kAcc];
-#pragma unroll
-    for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+    double acc[kAcc];                                       // zeroed only after the association: nothing of pass 2 is live during pass 1
     const bool single = e0 + estride >= n_waves;            // one entry for this wave (every scan up to 262 144 points): its point stays in registers
     if (single) {
         if (e0 < n_waves) {
@@ -1053,7 +1056,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
                 if (valid0) plane0 = G((const v4f*)cp->plane_cache)[chunk.x + lane];
             }
             if (HOOK) clk1 = wall_clock64();
+#pragma unroll
+            for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
             if (valid0) linearise_point<HOOK>(cp, T, sc6, chunk.x + lane, px, py, pz, plane0, acc);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
         }
     } else {
     // ---- pass 1: associate
@@ -1073,6 +1081,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     if (HOOK) clk1 = wall_clock64();
 
     // ---- pass 2: linearise
+#pragma unroll
+    for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
     for (int e = e0; e < n_waves; e += estride)
         linearise_chunk<HOOK>(cp, T, sc6, make_int2(tb[e].x, tb[e].y), lane, acc);
     }

@@ -166,6 +166,19 @@ def load_library(path: str | None = None) -> C.CDLL:
     return L
 
 
+def kernel_source_sha() -> str:
+    """sha256 over the kernel sources (liorf_amd/csrc): measurements kept under profiles/ are stamped with it so that
+    bench.py can tell whether they were taken on the kernels it is running."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def default_params(**kw) -> Params:
     p = Params()
     load_library().s2m_default_params(C.byref(p))

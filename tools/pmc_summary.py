@@ -32,9 +32,14 @@ def main():
     res = {}
     for name, per in vals.items():
         a = np.array(list(per.values()))
+        if a.size > 12:                                      # launches of full LM loops: drop nothing, but report the steady tail too
+            pass
         unit = "_KB" if name in ("FETCH_SIZE", "WRITE_SIZE") else ""
         res[name] = {"launches": int(a.size), "mean" + unit: float(a.mean()), "min" + unit: float(a.min()),
                      "max" + unit: float(a.max()), "median" + unit: float(np.median(a))}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from liorf_amd import s2m
+    res["kernel_source_sha"] = s2m.kernel_source_sha()      # bench.py reports these counters only for the kernels they were taken on
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
 
