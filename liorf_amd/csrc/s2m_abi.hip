@@ -47,7 +47,7 @@ struct s2m_context {
     // map side
     DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
     // scan side
-    DevBuf raw_scan, qx, qy, qz, qperm, npos, nbr, cert, aux, plane_cache, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of;
+    DevBuf raw_scan, qx, qy, qz, qperm, npos, nbr, cert, aux, plane_cache, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of, q_block_hist;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
     // voxel-grid stages that feed the path (section 8(f) F1/F2): staging for host clouds, transformed key frames, filtered clouds
@@ -309,14 +309,17 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     if ((rc = ensure(h, h->q_rank_of, sizeof(int32_t) * n))) return rc;
 
     const int nb = ((int)n + 255) / 256;
-    // q_counts is all zero here: cleared at creation and again by every k_polar_scan
-    hipLaunchKernelGGL(k_polar_count, dim3(((int)n + kPolarBlock - 1) / kPolarBlock), dim3(kPolarBlock), 0, h->stream, d_pts, stride, (int)n,
-                       h->q_cell_of.as<int32_t>(), h->q_rank_of.as<int32_t>(), h->q_counts.as<int32_t>());
+    const int npb = ((int)n + kPolarBlock - 1) / kPolarBlock;
+    if ((rc = ensure(h, h->q_block_hist, sizeof(int32_t) * (size_t)kPolarCells * (size_t)npb))) return rc;
+    hipLaunchKernelGGL(k_polar_count, dim3(npb), dim3(kPolarBlock), 0, h->stream, d_pts, stride, (int)n,
+                       h->q_cell_of.as<int32_t>(), h->q_rank_of.as<int32_t>(), h->q_block_hist.as<int32_t>());
+    hipLaunchKernelGGL(k_polar_prefix, dim3(kPolarCells / 64), dim3(1024), 0, h->stream, h->q_block_hist.as<int32_t>(), npb,
+                       h->q_counts.as<int32_t>());
     hipLaunchKernelGGL(k_polar_scan, dim3(1), dim3(1024), 0, h->stream,
                        h->q_counts.as<int32_t>(), h->q_cell_start.as<int32_t>());
     hipLaunchKernelGGL(k_scatter_scan, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
                        (const int32_t*)h->q_cell_of.as<int32_t>(), (const int32_t*)h->q_rank_of.as<int32_t>(),
-                       (const int32_t*)h->q_cell_start.as<int32_t>(),
+                       (const int32_t*)h->q_cell_start.as<int32_t>(), (const int32_t*)h->q_block_hist.as<int32_t>(),
                        h->qx.as<float>(), h->qy.as<float>(), h->qz.as<float>(), h->qperm.as<int32_t>(),
                        h->cert.as<float4>(), h->aux.as<int4>());
     S2M_HIP(h, hipGetLastError());
@@ -654,7 +657,7 @@ int s2m_destroy(s2m_handle h)
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
-                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->npos, &h->nbr, &h->cert, &h->aux, &h->plane_cache, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->npos, &h->nbr, &h->cert, &h->aux, &h->plane_cache, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of, &h->q_block_hist,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out,
                        &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds,

@@ -251,34 +251,73 @@ __device__ __forceinline__ int polar_cell(float x, float y)
     return (int)hilbert128((uint32_t)ab, (uint32_t)rb);
 }
 
-// Histogram with per-point rank.  Device-scope returning atomics are served memory-side on this
-// multi-die part (~27 us for 120 k of them), so every workgroup of 1024 points first ranks its
-// points in an LDS histogram and then reserves one range per non-empty cell with a single global
-// atomic: consecutive input points (acquisition order, or the voxel filter's x-rows) share cells,
-// which cuts the global atomics by an order of magnitude.
+// Histogram with per-point rank, DETERMINISTIC: the position of a scan point in the locality order depends on the
+// input alone, never on the order in which atomics happen to arrive - so the wave partition, the summation order of the
+// normal equations and with them every bit of a registration's result are reproducible from run to run.
+//   * inside a wave, points of the same cell are ranked by lane (match loop over the distinct cells of the wave);
+//   * the 16 waves of a workgroup add their cell counts to the workgroup's LDS histogram one after the other;
+//   * workgroup b writes its histogram as row b of a table; k_polar_prefix turns every column into an exclusive prefix
+//     over the workgroups (rank of the workgroup's first point in that cell) and the cell totals.
+// (Device-scope returning atomics, the obvious alternative, are also served memory-side on this multi-die part: 120 k
+// of them cost 27 us.)
 constexpr int kPolarBlock = 1024;
 __global__ __launch_bounds__(kPolarBlock) void k_polar_count(const unsigned char* __restrict__ pts, size_t stride, int n,
                                                              int32_t* __restrict__ cell_of, int32_t* __restrict__ rank_of,
-                                                             int32_t* __restrict__ counts)
+                                                             int32_t* __restrict__ block_hist)
 {
     __shared__ int32_t hist[kPolarCells];
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int k = t; k < kPolarCells; k += kPolarBlock) hist[k] = 0;
-    __syncthreads();
     const int i = blockIdx.x * kPolarBlock + t;
-    int c = 0, r = 0;
+    int c = -1;
     if (i < n) {
         const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
         c = polar_cell(p[0], p[1]);
-        r = atomicAdd(&hist[c], 1);
     }
-    __syncthreads();
-    for (int k = t; k < kPolarCells; k += kPolarBlock) {
-        const int cnt = hist[k];
-        if (cnt) hist[k] = atomicAdd(&counts[k], cnt);          // first rank of this workgroup's points in cell k
+    // rank among the lanes of this wave that share the cell, the group's size and its first lane
+    int r_in = 0, cnt = 0, leader = lane;
+    unsigned long long todo = __ballot(c >= 0);
+    while (todo) {
+        const int first = (int)__builtin_ctzll(todo);
+        const int v = __builtin_amdgcn_readlane(c, first);
+        const unsigned long long same = __ballot(c == v);
+        if (c == v) { r_in = __popcll(same & ((1ull << lane) - 1ull)); cnt = __popcll(same); leader = first; }
+        todo &= ~same;
     }
+    int base = 0;
+    for (int w = 0; w < kPolarBlock / 64; w++) {
+        __syncthreads();
+        if (wave == w && c >= 0 && leader == lane) { base = hist[c]; hist[c] = base + cnt; }     // distinct cells per leader: no conflict
+    }
+    base = __shfl(base, leader, 64);
     __syncthreads();
-    if (i < n) { cell_of[i] = c; rank_of[i] = hist[c] + r; }
+    if (i < n) { cell_of[i] = c; rank_of[i] = base + r_in; }
+    int32_t* row = block_hist + (size_t)blockIdx.x * kPolarCells;
+    for (int k = t; k < kPolarCells; k += kPolarBlock) row[k] = hist[k];
+}
+
+// Column-wise exclusive prefix of the workgroup histograms over the workgroups, in place, and the cell totals.
+// 64 columns x 16 segments of workgroups per 1024 threads: consecutive lanes read consecutive columns.
+__global__ __launch_bounds__(1024) void k_polar_prefix(int32_t* __restrict__ H, int nb, int32_t* __restrict__ counts)
+{
+    __shared__ int32_t seg[16][64];
+    const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;
+    const int per = (nb + 15) / 16, b0 = min(s * per, nb), b1 = min(b0 + per, nb);
+    int32_t sum = 0;
+    for (int b = b0; b < b1; b++) sum += H[(size_t)b * kPolarCells + col];
+    seg[s][lane] = sum;
+    __syncthreads();
+    int32_t run = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { const int32_t v = seg[q][lane]; run += (q < s) ? v : 0; total += v; }
+    if (s == 0) counts[col] = total;
+    for (int b = b0; b < b1; b++) {
+        const size_t at = (size_t)b * kPolarCells + col;
+        const int32_t v = H[at];
+        H[at] = run;
+        run += v;
+    }
 }
 
 // exclusive scan of the 16384 polar cell counts by one workgroup (16 per thread); the counts are
@@ -415,14 +454,16 @@ __global__ void k_scatter_map(const unsigned char* __restrict__ pts, size_t stri
 
 __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t stride, int n,
                                const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
-                               const int32_t* __restrict__ cell_start,
+                               const int32_t* __restrict__ cell_start, const int32_t* __restrict__ block_hist,
                                float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz,
                                int32_t* __restrict__ qperm, float4* __restrict__ cert, int4* __restrict__ aux)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
-    int pos = cell_start[cell_of[i]] + rank_of[i];
+    const int c = cell_of[i];
+    // first point of the cell + points of the cell in earlier workgroups of k_polar_count + rank inside the workgroup
+    int pos = cell_start[c] + block_hist[(size_t)(i / kPolarBlock) * kPolarCells + c] + rank_of[i];
     if ((unsigned)pos >= (unsigned)n) return;            // cannot happen while the histogram is consistent
     qx[pos] = p[0]; qy[pos] = p[1]; qz[pos] = p[2]; qperm[pos] = i;
     cert[pos] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // a new scan: no certificate (slack 0), no neighbour tuple, no plane

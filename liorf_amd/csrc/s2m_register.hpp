@@ -415,7 +415,9 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         const int tile_cap = kTilePts;
         const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
         const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
-        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * nC && (nC > kServeLanes || (ablate & 128));
+        // (a short wave - 8, 16 or 32 points of a split chunk - whose lanes all search stages its tile and shares the sweeps)
+        const bool all_of_short = chunk.y <= 32 && cmask == ((1ull << chunk.y) - 1ull);
+        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * max(nC, 8) && (nC > kServeLanes || all_of_short || (ablate & 128));
         if (HOOK && !tile) prof.why = 1;
         int nt = 0;                                       // tile fill, wave-uniform
         for (int rg = 0; rg < R && tile; rg += 64) {

@@ -103,3 +103,28 @@ def test_dense_clump_and_scattered_queries_under_every_path(cfg_small, monkeypat
             _check(gpu, orc, p)
         gpu.close()
         orc.close()
+
+
+def test_results_are_bitwise_reproducible(cfg_kitti64):
+    """The scan's locality order is a function of the input alone (k_polar_count ranks without racing atomics), so the wave
+    partition and the summation order of the normal equations are too: two handles, or two runs on one handle, give the
+    same bits - normal equations, every pose of the trace, the final result."""
+    m, s = synth.to_xyzi(cfg_kitti64["map"]), synth.to_xyzi(cfg_kitti64["scan"])
+    runs = []
+    for rep in range(3):
+        g = s2m.MapOptimizationS2M() if rep != 1 else runs[0][0]
+        if rep != 1:
+            g.setInputCloud(m)
+        g.setScan(s)
+        AtA, AtB, n = g.normal_eq(cfg_kitti64["pose_init"])
+        g.setScan(s)
+        g.transformTobeMapped = cfg_kitti64["pose_init"].copy()
+        r = g.scan2MapOptimization()
+        tr = np.array([t.pose[:] + t.delta[:] for t in g.trace()], np.float32)
+        runs.append((g, AtA.copy(), AtB.copy(), n, np.array(r.pose, np.float32), tr, r.iters_run))
+    for k in (1, 2):
+        assert runs[k][3] == runs[0][3] and runs[k][6] == runs[0][6]
+        for j in (1, 2, 4, 5):
+            assert np.array_equal(runs[k][j].view(np.uint32), runs[0][j].view(np.uint32)), (k, j)
+    runs[0][0].close()
+    runs[2][0].close()
