@@ -56,11 +56,14 @@ class RecordGatherer:
         self.h_send.fill_(float("nan"))
         if mine.shape[0]:
             self.h_send[: mine.shape[0]] = torch.from_numpy(mine)
-        if self.world == 1:
-            rows = self.h_send.numpy()
+        if self.world == 1 and not self.d_send.is_cuda:
+            rows = self.h_send.numpy()                     # a one-process CPU group: nothing to exchange
         else:
             self.d_send.copy_(self.h_send, non_blocking=True)
-            dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group)
+            if dist.is_initialized():
+                dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group)
+            else:
+                self.d_recv.copy_(self.d_send)             # no process group (single process): the table is this rank's rows
             self.h_recv.copy_(self.d_recv)                 # the one synchronising copy of the batch
             rows = self.h_recv.numpy()
         table = np.full((self.n_scans, RECORD_FLOATS), np.nan, np.float32)
