@@ -983,6 +983,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     // previous iteration is closed below
     int2 chunk = make_int2(0, 0);
     if (e0 < n_waves) { chunk.x = tb[e0].x; chunk.y = tb[e0].y; }
+    chunk.x = __builtin_amdgcn_readfirstlane(chunk.x);       // wave-uniform: scalar registers
+    chunk.y = __builtin_amdgcn_readfirstlane(chunk.y);
     float px = 0.0f, py = 0.0f, pz = 0.0f;
     v4f cert = { 0, 0, 0, 0 }, plane0 = { NAN, 0, 0, 0 };
     const bool valid0 = lane < chunk.y && chunk.x + lane < nq;
@@ -1069,7 +1071,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
     // ---- pass 1: associate
     for (int e = e0; e < n_waves; e += estride) {
         if (e != e0) {
-            chunk = make_int2(tb[e].x, tb[e].y);
+            chunk = make_int2(__builtin_amdgcn_readfirstlane(tb[e].x), __builtin_amdgcn_readfirstlane(tb[e].y));
             px = 0.0f; py = 0.0f; pz = 0.0f; cert = v4f{ 0, 0, 0, 0 };
             if (lane < chunk.y && chunk.x + lane < nq) {
                 const int i = chunk.x + lane;

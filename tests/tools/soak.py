@@ -47,7 +47,7 @@ def main():
         orc = O.Oracle(knn_backend=0, num_threads=8)
         orc.set_map(m); orc.set_scan(s)
         base = cfg["pose_gt"].astype(np.float32)
-        for scale in (0.0, 0.01, 0.3, 0.0):
+        for scale in (0.0, 0.01, 1e-4, 0.3, 1e-5, 2e-3, 0.0):
             d = rng.normal(0, 1, 6).astype(np.float32) * np.float32(scale) * np.array([0.05, 0.05, 0.05, 1, 1, 1], np.float32)
             idx, d2, flag, coeff = gpu.surfOptimization(base + d)
             oidx, od2, oflag, ocoeff = orc.surfOptimization(base + d)
