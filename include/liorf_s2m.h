@@ -203,6 +203,12 @@ int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, floa
  * and cost more than the steady state. */
 int  s2m_time_iterations(s2m_handle h, const float pose[6], int reps, float* ms_per_iter, int cap);
 
+/* Benchmark helper: mean duration (microseconds) of a k_register launch over `reps` whole LM loops as the fused loop issues them,
+ * measured with HIP events on the handle's stream around launch 0, launch 1, the run of back-to-back launches 2 .. max_iter-2 and
+ * the last launch - four event pairs per loop instead of max_iter, so the event packets do not break up the back-to-back dispatch
+ * (the gaps between consecutive launches are part of the figure). */
+int  s2m_time_loop_launches(s2m_handle h, const float pose[6], int reps, float* us_per_launch);
+
 /* Diagnostics: a full loop from `pose` (early_exit must be off), then `reps` back-to-back replays of its last registration
  * launch in the state the loop ended in; solve_prev != 0 closes the iteration before it in the launch's prologue each time
  * (the steady launch of the fused loop), 0 only rebuilds the transform.  Mean microseconds per replayed launch, gaps included. */

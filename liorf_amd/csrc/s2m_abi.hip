@@ -397,7 +397,10 @@ int push_state(s2m_context* h, const float pose[6])
 // `events`, if given, holds 2*n events recorded around every k_register launch.
 constexpr int kFuseMaxBlocks = 512;
 
-void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* events)
+// `events`, if given, holds 2*n events recorded around every k_register launch; with `coarse` only four pairs are recorded - around
+// launch 0, launch 1, the run of back-to-back launches 2 .. n-2 (slots 4, 5) and launch n-1 (slots 6, 7) - so that the event
+// packets do not break up the loop's back-to-back dispatch.
+void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* events, bool coarse = false)
 {
     const int n = h->prm.max_iter;
     DevState* st = h->state.as<DevState>();
@@ -410,9 +413,11 @@ void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* eve
         hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, const_cast<DevCtx*>(dc), st);
     }
     for (int L = 0; L < n; L++) {
-        if (events) (void)hipEventRecord(events[2 * L], h->stream);
+        const int slot = !coarse ? 2 * L : (L == 0 ? 0 : (L == 1 ? 2 : (L == n - 1 ? 6 : 4)));
+        const bool open = events && (!coarse || L <= 2 || L == n - 1), close = events && (!coarse || L <= 1 || L >= n - 2);
+        if (open) (void)hipEventRecord(events[slot], h->stream);
         hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, (fuse && L >= 2) ? 1 : 0);
-        if (events) (void)hipEventRecord(events[2 * L + 1], h->stream);
+        if (close) (void)hipEventRecord(events[slot + 1], h->stream);
         if (!fuse || L == 0 || L == n - 1) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
     }
 }
@@ -1170,6 +1175,38 @@ int s2m_debug_time_steady(s2m_handle h, const float pose[6], int reps, int solve
     float ms = 0;
     S2M_HIP(h, hipEventElapsedTime(&ms, h->ev_c, h->ev_d));
     *us_per_launch = ms * 1e3f / (float)reps;
+    return S2M_OK;
+}
+
+// Mean duration of a k_register launch over `reps` whole LM loops (max_iter >= 5, fused loop), gaps between the back-to-back
+// launches included: HIP events on the handle's stream around launch 0, launch 1, the run of launches 2 .. n-2 and launch n-1.
+int s2m_time_loop_launches(s2m_handle h, const float pose[6], int reps, float* us_per_launch)
+{
+    if (!h || !pose || reps < 1 || !us_per_launch) return S2M_ERR_INVALID_ARG;
+    if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
+    const int nit = h->prm.max_iter;
+    if (nit < 5) return fail(h, S2M_ERR_INVALID_ARG, "needs max_iter >= 5");
+    S2M_HIP(h, hipSetDevice(h->device));
+    int rc;
+    if ((rc = upload_ctx(h))) return rc;
+    while (h->iter_events.size() < 8) { hipEvent_t e; S2M_HIP(h, hipEventCreate(&e)); h->iter_events.push_back(e); }
+    const DevCtx* dc = h->dctx.as<DevCtx>();
+    double total_ms = 0.0;
+    for (int rep = 0; rep < reps; rep++) {
+        S2M_HIP(h, hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream));      // a new scan: no certificates, no neighbourhoods
+        S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int4) * h->n_q, h->stream));
+        if ((rc = push_state(h, pose))) return rc;
+        enqueue_loop(h, h->hctx.nblocks, dc, h->iter_events.data(), true);
+        h->hctx.density_pending = 0;
+        S2M_HIP(h, hipGetLastError());
+        S2M_HIP(h, hipStreamSynchronize(h->stream));
+        for (int k = 0; k < 4; k++) {
+            float ms = 0;
+            S2M_HIP(h, hipEventElapsedTime(&ms, h->iter_events[2 * k], h->iter_events[2 * k + 1]));
+            total_ms += ms;
+        }
+    }
+    *us_per_launch = (float)(total_ms * 1e3 / ((double)reps * nit));
     return S2M_OK;
 }
 

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
     "s2m_optimize_batch", "s2m_batch_set_scan", "s2m_optimize_batch_launch", "s2m_optimize_batch_collect", "s2m_batch_get_trace",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
-    "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile", "s2m_debug_time_steady",
+    "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile", "s2m_debug_time_steady", "s2m_time_loop_launches",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
     "s2m_transform_cloud",
     "s2m_icp_default_params", "s2m_icp_align", "s2m_debug_device_trig",
@@ -143,6 +143,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_time_iterations.argtypes = [vp, fp, C.c_int, fp, C.c_int]
     L.s2m_debug_wave_profile.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint64), C.c_size_t]
     L.s2m_debug_time_steady.argtypes = [vp, fp, C.c_int, C.c_int, fp]
+    L.s2m_time_loop_launches.argtypes = [vp, fp, C.c_int, fp]
     L.s2m_make_scancontext.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     szp = C.POINTER(C.c_size_t)
     for n in ("s2m_voxel_downsample", "s2m_voxel_downsample_device"):
@@ -167,15 +168,14 @@ def load_library(path: str | None = None) -> C.CDLL:
 
 
 def kernel_source_sha() -> str:
-    """sha256 over the kernel sources (liorf_amd/csrc): measurements kept under profiles/ are stamped with it so that
-    bench.py can tell whether they were taken on the kernels it is running."""
+    """sha256 over the device code of the registration path (the kernel headers of liorf_amd/csrc): measurements kept under
+    profiles/ are stamped with it so that bench.py can tell whether they were taken on the kernels it is running."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(_HERE, "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".h")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("s2m_kernels.hpp", "s2m_register.hpp", "s2m_types.h"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -478,6 +478,13 @@ class MapOptimizationS2M:
         out = np.zeros(64, np.float32)
         self._check(self.lib.s2m_time_iterations(self.h, _fp(p), reps, _fp(out), 64), "s2m_time_iterations")
         return out[:self.params.max_iter]
+
+    def time_loop_launches(self, pose, reps: int = 10) -> float:
+        """Mean k_register launch duration (us) over whole LM loops, four HIP-event pairs per loop (s2m_time_loop_launches)."""
+        p = np.ascontiguousarray(pose, np.float32)
+        us = C.c_float(0)
+        self._check(self.lib.s2m_time_loop_launches(self.h, _fp(p), reps, C.byref(us)), "s2m_time_loop_launches")
+        return us.value
 
     def time_steady(self, pose, reps: int = 200, solve_prev: bool = True) -> float:
         """Diagnostics: microseconds per replayed steady-state launch (s2m_debug_time_steady)."""
