@@ -88,10 +88,10 @@ def test_cpp_host_harness_builds_and_fails_loudly_without_gpu():
 
 
 def test_committed_bench_line_follows_the_contract():
-    """profiles/r01_bench_line.json is what `python bench.py` printed on the MI355X: one JSON object with the
+    """profiles/r02_bench_line.json is what `python bench.py` printed on the MI355X: one JSON object with the
     driver's keys plus the `roofline` and `cpu_baseline` objects."""
     import json
-    line = open(os.path.join(ROOT, "profiles", "r01_bench_line.json")).read().strip().splitlines()[-1]
+    line = open(os.path.join(ROOT, "profiles", "r02_bench_line.json")).read().strip().splitlines()[-1]
     d = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -102,6 +102,11 @@ def test_committed_bench_line_follows_the_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    # achieved = algorithmic bytes / mean launch duration; traffic (PMC, stamped) at least the algorithmic bytes
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / r["kernel_us"] / 1e3) / r["achieved"] < 1e-3
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    for k in ("ms_per_step_windows", "ms_per_scan_early_exit", "kernel_us_steady_back_to_back"):
+        assert k in d, k
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
