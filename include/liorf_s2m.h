@@ -224,7 +224,7 @@ int  s2m_debug_time_steady(s2m_handle h, const float pose[6], int reps, int solv
  * prior+box / row marking, points in the wave, staging, search; [13..15] path details; [16..22] wall clock
  * of the fused LM close: entry, partial sums reduced, normal equations, QR solved, update done, barrier
  * passed, transform built (0 when the launch closes nothing). Returns the number of waves written. */
-#define S2M_PROF_WORDS 24
+#define S2M_PROF_WORDS 32
 int  s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint64_t* out, size_t cap_waves);
 
 /* ---- The voxel-grid stages either side of the path ----------

@@ -56,6 +56,7 @@
 
 constexpr float kCertMargin = 2e-6f;   // metres; see tier A above
 constexpr float kNbrReach   = 0.15f;   // metres beyond the 5th neighbour that a search tries to cover with the neighbourhood ...
+constexpr float kTightBound = 0.62f;   // metres: a stored tuple whose 5th member is nearer than this now is taken to be (nearly) the answer
 constexpr float kNbrReachCold = 0.10f; // ... and beyond the gate when it has no tuple to start from (first launch of a scan)
 constexpr int   kWalkLanes = 64;       // a wave whose tile overflowed serves up to this many lanes one by one; beyond, every lane walks its own cells
 constexpr int   kNbr = kNbrCap;        // neighbourhood capacity (map positions per scan point)
@@ -164,6 +165,8 @@ struct WaveProf {
     int mode = 0;              // search path taken by the last entry that searched: 1 tile, 2 served, 3 tile overflow then served
     int n_a = 0, n_b = 0, n_c = 0;   // lanes settled by certificate / by re-measuring / by searching (summed over the wave's entries)
     int rows = 0, pts = 0, raw = 0, why = 0;
+    int n_fb = 0, reach_mm = 0, kq = 0, cmax = 0;   // tile path: lanes that fell back to the exact sweep, staged reach, lanes per point, longest list
+    unsigned long long ts[4] = { 0, 0, 0, 0 };   // stamps of the last entry that searched: search begins, tile staged, tile done, search done
 };
 
 // ------------------------------------------------------------------------------------------
@@ -350,7 +353,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     const bool searching = need && !settled;
     const unsigned long long cmask = __ballot(searching);
     if (cmask) {
-        if (HOOK) prof.n_c += __popcll(cmask);
+        if (HOOK) { prof.n_c += __popcll(cmask); prof.ts[0] = wall_clock64(); }
         if (searching) { nb_n = 0; nbr_ok = false; }
         // Upper bound of the 5th-neighbour distance: the old tuple measured at this pose (any 5 distinct map points would
         // do), capped at the gate.
@@ -404,7 +407,8 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         // (one whole cell past the nearest face of its own cell).  Every map point nearer than `be` is met.
         const float cover = (E - kSlabMargin) + fminf(fminf(fminf(gxm, gxp), fminf(gym, gyp)), fminf(gzm, gzp));
         const float sb = sqrtf(bound);
-        const float be = searching ? fminf(sb + (has_prior ? kNbrReach : kNbrReachCold), cover) : 0.0f;
+        const bool tight = has_prior && sb < kTightBound;  // see the level layout of the tile path
+        const float be = searching ? fminf(sb + (tight ? kNbrReach : kNbrReachCold), cover) : 0.0f;
         const float be2 = fmaxf(be * be, bound);          // rows / cells are selected with this; never tighter than the bound itself
         const float rmax2 = wave_max_f32(searching ? be2 : 0.0f);
 
@@ -483,6 +487,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             }
         }
 
+        if (HOOK) prof.ts[1] = wall_clock64();
         if (tile) {
             wave_lds_sync();
             if (HOOK) { prof.mode = 1; prof.pts = nt; }
@@ -490,7 +495,9 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             // reach down to the bound itself; without one: the reach, the gate, and fractions of the gate.  The neighbourhood
             // becomes the widest of them that holds at most kNbr points.
             float tl[kLevels];
-            if (has_prior) {
+            // (a tuple to start from that has gone stale - the pose moved far, its 5th member is now near or beyond the gate - says
+            // little about where the 5th neighbour really is: such a lane counts like one without a tuple, in fractions of its bound)
+            if (tight) {
                 const float st[kLevels] = { kNbrReach, 0.10f, 0.06f, 0.03f, 0.012f, 0.0f };
 #pragma unroll
                 for (int k = 0; k < kLevels; k++) { const float rr_ = fminf(sb + st[k], be); tl[k] = fmaxf(rr_ * rr_, bound); }
@@ -498,7 +505,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             } else {
                 const float fr[kLevels] = { 0.0f, 1.0f, 1.0f / 1.6f, 1.0f / 2.56f, 1.0f / 4.1f, 1.0f / 6.55f };
 #pragma unroll
-                for (int k = 0; k < kLevels; k++) tl[k] = fminf(gatef * fr[k], be2);
+                for (int k = 0; k < kLevels; k++) tl[k] = fminf(bound * fr[k], be2);      // bound = the gate without a tuple
                 tl[0] = be2;
             }
             // A wave of a split chunk holds 32, 16 or 8 points in its first lanes (they sit in dense parts of the map and
@@ -546,7 +553,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             float lvl2 = ql_[kLevels - 1];
 #pragma unroll
             for (int k = kLevels - 2; k >= 0; k--) { const bool fits = c[k] <= kNbr; lvl2 = fits ? ql_[k] : lvl2; cl = fits ? c[k] : cl; }
-            const bool q_prior = (kq > 1) ? (__shfl((int)has_prior, lane & (nslot - 1), 64) != 0) : has_prior;
+            const bool q_prior = (kq > 1) ? (__shfl((int)tight, lane & (nslot - 1), 64) != 0) : tight;
             const bool q_search = (kq > 1) ? (__shfl((int)searching, lane & (nslot - 1), 64) != 0) : searching;
             const int c_gate = q_prior ? c[kLevels - 1] : c[1];
             const bool q_fallback = q_search && (cl > kNbr || (cl < 5 && c_gate >= 5));
@@ -554,6 +561,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             // ---- the neighbourhood: tile slots inside the level, written down in a second branch-free sweep; the nearest
             // tile point beyond the level tells how far the neighbourhood really reaches
             const bool lister = searching && !fallback;
+            if (HOOK) { prof.n_fb = __popcll(__ballot(fallback)); prof.reach_mm = (int)(rr * 1000.0f); prof.kq = kq; }
             int cc = 0;
             float mo = INFINITY;
             if (q_search && !q_fallback) {
@@ -595,6 +603,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             // those six in front
             {
                 const int cmax = wave_max_i32(cc);
+                if (HOOK) prof.cmax = cmax;
                 Top6k t;
 #pragma unroll
                 for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
@@ -657,6 +666,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         // candidates (all map points of those cells) are read 64 at a time, their keys kept in the wave's LDS area, and seven
         // rounds of "smallest key above the last one" pick the six nearest and the distance of the seventh: the lane's new
         // neighbourhood and its radius.  ~2 dependent round trips per served lane.
+        if (HOOK) prof.ts[2] = wall_clock64();
         unsigned long long pend = (tile || nC > kWalkLanes) ? 0ull : cmask;
         unsigned long long walk = (!tile && nC > kWalkLanes) ? cmask : 0ull;      // lanes that walk their own cells (below)
         if (pend) {
@@ -751,6 +761,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 settled = true;
             }
         }
+        if (HOOK) prof.ts[3] = wall_clock64();
     }
 
     // ---- the outcome for every lane that re-measured or searched
@@ -1117,9 +1128,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
         d[0] = tk_start; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
         d[4] = (unsigned long long)prof.mode; d[5] = (unsigned long long)prof.rows; d[6] = (unsigned long long)prof.pts; d[7] = (unsigned long long)prof.raw;
         d[8] = (unsigned long long)prof.n_a; d[9] = (unsigned long long)prof.n_b; d[10] = (unsigned long long)chunk.y; d[11] = (unsigned long long)prof.n_c;
-        d[12] = 0; d[13] = (unsigned long long)prof.why; d[14] = 0; d[15] = 0;
+        d[12] = prof.ts[0]; d[13] = (unsigned long long)prof.why; d[14] = prof.ts[1]; d[15] = prof.ts[2];
         // fused LM close (solve_prev launches): entry, partial sums reduced, normal equations, QR, update, barrier, T built
-        d[16] = lm_stamps[5]; d[17] = lm_stamps[0]; d[18] = lm_stamps[1]; d[19] = lm_stamps[2]; d[20] = lm_stamps[3]; d[21] = lm_stamps[4]; d[22] = lm_stamps[6]; d[23] = 0;
+        d[16] = lm_stamps[5]; d[17] = lm_stamps[0]; d[18] = lm_stamps[1]; d[19] = lm_stamps[2]; d[20] = lm_stamps[3]; d[21] = lm_stamps[4]; d[22] = lm_stamps[6]; d[23] = prof.ts[3];
+        d[24] = (unsigned long long)prof.n_fb; d[25] = (unsigned long long)prof.reach_mm; d[26] = (unsigned long long)prof.kq; d[27] = (unsigned long long)prof.cmax;
     }
     __syncthreads();
     if (tid < kAcc) {

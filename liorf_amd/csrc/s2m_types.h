@@ -11,7 +11,7 @@ constexpr int kBlock = 512;            // threads per workgroup of the registrat
 constexpr int kAcc = 28;               // 21 upper-triangular JtJ + 6 Jtr + 1 correspondence count
 constexpr int kFinThreads = 1024;      // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
-constexpr int kProfWords = 24;         // uint64 words per wave written by the diagnostics variant of k_register
+constexpr int kProfWords = 32;         // uint64 words per wave written by the diagnostics variant of k_register
 constexpr int kBlocksQuantum = 8;      // graph cache key granularity (workgroups)
 constexpr int kNbrCap = 16;           // neighbourhood capacity per scan point (s2m_register.hpp: kNbr)
 constexpr int kMaxBlocks = 512;        // largest k_register grid: two 8-wave workgroups on each of the 256 CUs, all co-resident

@@ -494,11 +494,11 @@ class MapOptimizationS2M:
         return us.value
 
     def wave_profile(self, pose, launches: int = 3) -> np.ndarray:
-        """Diagnostics: (n_waves, 24) uint64 per-wave stamps/stats of one k_register pass (include/liorf_s2m.h);
+        """Diagnostics: (n_waves, 32) uint64 per-wave stamps/stats of one k_register pass (include/liorf_s2m.h);
         launches < 0 records launch number -launches of a real LM loop."""
         p = np.ascontiguousarray(pose, np.float32)
         cap = (self.laserCloudSurfLastDSNum + 15) // 16 + 256
-        out = np.zeros((cap, 24), np.uint64)
+        out = np.zeros((cap, 32), np.uint64)
         n = self.lib.s2m_debug_wave_profile(self.h, _fp(p), launches, out.ctypes.data_as(C.POINTER(C.c_uint64)), cap)
         if n < 0:
             self._check(n, "s2m_debug_wave_profile")

@@ -39,9 +39,22 @@ for mode in [m for m in os.environ.get("S2M_WAVES", "").split(",") if m]:
             print("   %-11s waves: %5d (%.1f%%) associate med %.2f p99 %.2f max %.2f us; tile pts med %d max %d; searching lanes med %d" % (
                 nm, sel.sum(), 100.0 * sel.mean(), np.median(p1[sel]), np.percentile(p1[sel], 99), p1[sel].max(),
                 np.median(w[sel, 6]), w[sel, 6].max(), np.median(w[sel, 11])))
+    srch = w[:, 12] > 0
+    if srch.any():
+        beg = np.maximum(w[:, 22], w[:, 0])
+        for nm, a in (("before search", w[:, 12] - beg), ("stage tile", w[:, 14] - w[:, 12]), ("tile count/list/six", w[:, 15] - w[:, 14]),
+                      ("serve/walk", w[:, 23] - w[:, 15]), ("tail (fetch, plane, stores)", w[:, 1] - w[:, 23])):
+            a = us(a[srch])
+            print("   searching waves, %-28s med %.2f p90 %.2f p99 %.2f max %.2f us" % (nm, np.median(a), np.percentile(a, 90), np.percentile(a, 99), a.max()))
+    tl = w[:, 4] == 1
+    if tl.any():
+        print("   tile waves: fallback lanes total %d (in %d waves); reach med %d max %d mm; kq counts %s; longest list med %d max %d" % (
+            w[tl, 24].sum(), (w[tl, 24] > 0).sum(), np.median(w[tl, 25]), w[tl, 25].max(),
+            dict(zip(*np.unique(w[tl, 26], return_counts=True))), np.median(w[tl, 27]), w[tl, 27].max()))
     print("   slowest waves: total associate path rows pts raw why lanesA lanesB lanesC n")
     for i in np.argsort(-tot)[:8]:
-        print("      %.2f %.2f %d %d %d %d %d %d %d %d %d" % (tot[i], p1[i], w[i, 4], w[i, 5], w[i, 6], w[i, 7], w[i, 13], w[i, 8], w[i, 9], w[i, 11], w[i, 10]))
+        print("      %.2f %.2f %d %d %d %d %d %d %d %d %d   fb %d reach %d kq %d cmax %d stages %s" % (tot[i], p1[i], w[i, 4], w[i, 5], w[i, 6], w[i, 7], w[i, 13], w[i, 8], w[i, 9], w[i, 11], w[i, 10], w[i, 24], w[i, 25], w[i, 26], w[i, 27],
+              " ".join("%.1f" % us(v) for v in (w[i, 12] - max(w[i, 22], w[i, 0]), w[i, 14] - w[i, 12], w[i, 15] - w[i, 14], w[i, 23] - w[i, 15], w[i, 1] - w[i, 23])) if w[i, 12] > 0 else "-"))
     if w[:, 16].max() > 0:
         names = ["entry", "partials reduced", "normal equations", "QR solved", "update done", "barrier passed", "T built"]
         prev = w[:, 0]
