@@ -508,21 +508,35 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 for (int k = 0; k < kLevels; k++) tl[k] = fminf(bound * fr[k], be2);      // bound = the gate without a tuple
                 tl[0] = be2;
             }
-            // A wave of a split chunk holds 32, 16 or 8 points in its first lanes (they sit in dense parts of the map and
-            // have the biggest tiles); when all of them search, the idle lanes join in: kq = 2, 4 or 8 lanes share a point,
-            // each sweeps every kq-th tile point, and the results are combined across the group.
-            const bool packed = cmask == ((chunk.y >= 64) ? ~0ull : ((1ull << chunk.y) - 1ull));
-            const int kq = !packed ? 1 : ((chunk.y > 32) ? 1 : ((chunk.y > 16) ? 2 : ((chunk.y > 8) ? 4 : 8)));
+            // Idle lanes join in.  With nC <= 32 searching lanes, kq = 2, 4 or 8 lanes share one searching point: the wave is
+            // cut into kq parts of nslot = 64 / kq lanes, lane l works for slot l % nslot - the searching lane of that rank -
+            // and sweeps every kq-th tile point; counts, lists and the rim are combined across the parts, and the searching
+            // lane of rank r picks its result up from lane r (part 0 of its slot).  kq = 1: every lane works for itself.
+            const int kq = (nt <= 16 || nC > 32) ? 1 : ((nC > 16) ? 2 : ((nC > 8) ? 4 : 8));
             const int nslot = 64 / kq, part = lane / nslot;
+            int own = lane;                                   // the searching lane this lane works for
+            int col = lane;                                   // the lane whose results (and LDS column) are mine: my rank among the searching lanes
+            bool q_search = searching;
+            if (kq > 1) {
+                int* lown = reinterpret_cast<int*>(lrows);    // (the row table is not needed any more)
+                const int rank = __popcll(cmask & ((1ull << lane) - 1ull));
+                if (searching) lown[rank] = lane;
+                wave_lds_sync();
+                const int s_ = lane & (nslot - 1);
+                q_search = s_ < nC;
+                own = q_search ? lown[s_] : lane;
+                col = searching ? rank : lane;
+            }
             float qx_ = sx, qy_ = sy, qz_ = sz;
             float ql_[kLevels];
 #pragma unroll
             for (int k = 0; k < kLevels; k++) ql_[k] = tl[k];
+            bool q_prior = tight;
             if (kq > 1) {
-                const int src = lane & (nslot - 1);
-                qx_ = __shfl(sx, src, 64); qy_ = __shfl(sy, src, 64); qz_ = __shfl(sz, src, 64);
+                qx_ = __shfl(sx, own, 64); qy_ = __shfl(sy, own, 64); qz_ = __shfl(sz, own, 64);
 #pragma unroll
-                for (int k = 0; k < kLevels; k++) ql_[k] = __shfl(tl[k], src, 64);
+                for (int k = 0; k < kLevels; k++) ql_[k] = __shfl(tl[k], own, 64);
+                q_prior = __shfl((int)tight, own, 64) != 0;
             }
             // ---- count the tile points inside the kLevels radii of every searching lane (branch-free)
             int c[kLevels];
@@ -553,18 +567,14 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             float lvl2 = ql_[kLevels - 1];
 #pragma unroll
             for (int k = kLevels - 2; k >= 0; k--) { const bool fits = c[k] <= kNbr; lvl2 = fits ? ql_[k] : lvl2; cl = fits ? c[k] : cl; }
-            const bool q_prior = (kq > 1) ? (__shfl((int)tight, lane & (nslot - 1), 64) != 0) : tight;
-            const bool q_search = (kq > 1) ? (__shfl((int)searching, lane & (nslot - 1), 64) != 0) : searching;
             const int c_gate = q_prior ? c[kLevels - 1] : c[1];
             const bool q_fallback = q_search && (cl > kNbr || (cl < 5 && c_gate >= 5));
-            const bool fallback = searching && q_fallback;                 // (owner lanes: part 0 of their group)
+            const bool q_lister = q_search && !q_fallback;
             // ---- the neighbourhood: tile slots inside the level, written down in a second branch-free sweep; the nearest
             // tile point beyond the level tells how far the neighbourhood really reaches
-            const bool lister = searching && !fallback;
-            if (HOOK) { prof.n_fb = __popcll(__ballot(fallback)); prof.reach_mm = (int)(rr * 1000.0f); prof.kq = kq; }
             int cc = 0;
             float mo = INFINITY;
-            if (q_search && !q_fallback) {
+            if (q_lister) {
                 int j = part;
                 for (; j + 3 * kq < nt; j += 4 * kq) {        // four LDS reads in flight
                     const v4f m0 = lpts[j], m1 = lpts[j + kq], m2 = lpts[j + 2 * kq], m3 = lpts[j + 3 * kq];
@@ -584,19 +594,26 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                     mo = fminf(mo, (d > lvl2) ? d : INFINITY);
                 }
             }
+            bool fallback = searching && q_fallback;
             if (kq > 1) {
-                // the group's lists go into the owner's column
+                // the lists of a slot's parts go into the column of its part 0, where the searching lane finds them
                 wave_lds_sync();
                 for (int m = nslot; m < 64; m <<= 1) mo = fminf(mo, __shfl_xor(mo, m, 64));
                 int tot = cc;
                 for (int pp = 1; pp < kq; pp++) {
                     const int n_pp = __shfl(cc, (lane & (nslot - 1)) + pp * nslot, 64);
-                    if (part == 0 && lister) {
+                    if (part == 0 && q_lister) {
                         for (int k = 0; k < n_pp && tot < kNbr; k++) { lcand[tot * 64 + lane] = lcand[k * 64 + lane + pp * nslot]; tot++; }
                     }
                 }
-                cc = (part == 0) ? tot : 0;
+                cc = __shfl(tot, col, 64);
+                mo = __shfl(mo, col, 64);
+                lvl2 = __shfl(lvl2, col, 64);
+                const int fb_col = __shfl((int)q_fallback, col, 64);       // (not inside a && / ?: - every lane has to take part in a shuffle)
+                fallback = searching & (fb_col != 0);
             }
+            const bool lister = searching && !fallback;
+            if (HOOK) { prof.n_fb = __popcll(__ballot(fallback)); prof.reach_mm = (int)(rr * 1000.0f); prof.kq = kq; }
             if (!lister) cc = 0;
             wave_lds_sync();
             // ---- its six nearest (the lanes insert their k-th member together), then the neighbourhood goes to memory with
@@ -608,9 +625,9 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 #pragma unroll
                 for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
                 uint64_t k7 = kKeyInf;
-                v4f mk = lpts[min((int)lcand[lane], kTilePts - 1)];
+                v4f mk = lpts[min((int)lcand[col], kTilePts - 1)];
                 for (int k = 0; k < cmax; k++) {
-                    const v4f mn_ = lpts[min((int)lcand[min(k + 1, kCand - 1) * 64 + lane], kTilePts - 1)];
+                    const v4f mn_ = lpts[min((int)lcand[min(k + 1, kCand - 1) * 64 + col], kTilePts - 1)];
                     float d2;
                     const uint64_t key = make_key(mk, sx, sy, sz, d2);
                     const uint64_t out = top6k_insert(t, (lister && k < cc) ? key : kKeyInf);
@@ -629,7 +646,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                     for (int k = 0; k < 6; k++)
                         if (key_hi(t.key[k]) < 0x7f800000u) { nbrp[(size_t)slot * nq + i] = (int)key_lo(t.key[k]); slot++; }
                     for (int k = 0; k < cc; k++) {
-                        const int p = __float_as_int(lpts[min((int)lcand[k * 64 + lane], kTilePts - 1)].w);
+                        const int p = __float_as_int(lpts[min((int)lcand[k * 64 + col], kTilePts - 1)].w);
                         bool in6 = false;
 #pragma unroll
                         for (int j = 0; j < 6; j++) in6 = in6 || (uint32_t)p == key_lo(t.key[j]);
