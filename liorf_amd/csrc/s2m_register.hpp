@@ -1096,7 +1096,30 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
             for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
         }
     } else {
+    // A wave with several entries first asks whether any of its points needs more than its certificate: in the steady state
+    // of the loop none does, and the wave goes straight to the residuals (nothing of the association is live there).
+    bool any_need = HOOK;
+    if (!HOOK) {
+        for (int e = e0; e < n_waves; e += estride) {
+            const int2 en = make_int2(__builtin_amdgcn_readfirstlane(tb[e].x), __builtin_amdgcn_readfirstlane(tb[e].y));
+            const int i = en.x + lane;
+            bool need = false;
+            if (lane < en.y && i < nq) {
+                const float qx = G(cp->qx)[i], qy = G(cp->qy)[i], qz = G(cp->qz)[i];
+                const v4f ce = G((const v4f*)cp->cert)[i];
+                const float sx = ((T[0] * qx + T[1] * qy) + T[2]  * qz) + T[3];
+                const float sy = ((T[4] * qx + T[5] * qy) + T[6]  * qz) + T[7];
+                const float sz = ((T[8] * qx + T[9] * qy) + T[10] * qz) + T[11];
+                const bool fin = (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
+                const float ex = sx - ce.x, ey = sy - ce.y, ez = sz - ce.z;
+                const float eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
+                need = fin && !(!(ablate & 1) && (eps < ce.w));
+            }
+            any_need = any_need || (__ballot(need) != 0ull);
+        }
+    }
     // ---- pass 1: associate
+    if (any_need)
     for (int e = e0; e < n_waves; e += estride) {
         if (e != e0) {
             chunk = make_int2(__builtin_amdgcn_readfirstlane(tb[e].x), __builtin_amdgcn_readfirstlane(tb[e].y));
