@@ -95,6 +95,7 @@ struct s2m_context {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_up = nullptr;
     float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
     int base_parts = 1;
+    bool big_blocks = true;            // env S2M_BIG_BLOCKS=0: 8-wave workgroups whatever the scan size (A/B measurements)
     int density_raw = 320;             // box points above which a wave asks for a finer cut (env S2M_DENSITY_RAW, 0 = off)
     bool opt_pending = false;
     bool scan_timing_pending = false;
@@ -278,7 +279,10 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     nblocks = ((nblocks + kBlocksQuantum - 1) / kBlocksQuantum) * kBlocksQuantum;
     if (nblocks == 0) nblocks = kBlocksQuantum;
     const int table_cap = nblocks * NW;                   // wave-table entries: every chunk plus the budget for split chunks
-    nblocks = std::min(nblocks, kMaxBlocks);               // the grid stays co-resident: waves loop over the table
+    // more entries than one 8-wave workgroup per CU holds: 16-wave workgroups, one per CU (s2m_types.h, kBigWaves)
+    const int wpb = (h->big_blocks && n_chunks * base_parts > (kMaxBlocks / 2) * NW) ? kBigWaves : NW;
+    nblocks = std::min((table_cap + wpb - 1) / wpb, kMaxBlocks * NW / wpb);   // the grid stays co-resident: waves loop over the table
+    h->hctx.wpb = wpb;
     h->hctx.nblocks = nblocks;
     h->hctx.table_cap = table_cap;
     h->ctx_dirty = true;
@@ -400,6 +404,19 @@ constexpr int kFuseMaxBlocks = 512;
 // `events`, if given, holds 2*n events recorded around every k_register launch; with `coarse` only four pairs are recorded - around
 // launch 0, launch 1, the run of back-to-back launches 2 .. n-2 (slots 4, 5) and launch n-1 (slots 6, 7) - so that the event
 // packets do not break up the loop's back-to-back dispatch.
+// one k_register launch in the workgroup shape of the resident scan (DevCtx::wpb)
+inline void launch_register(s2m_context* h, bool hook, int nblocks, const DevCtx* dc, DevState* st, int L, int solve_prev)
+{
+    constexpr int NW = kBlock / 64;
+    if (h->hctx.wpb == kBigWaves) {
+        if (hook) hipLaunchKernelGGL((k_register<true, kBigWaves>), dim3(nblocks), dim3(kBigWaves * 64), 0, h->stream, dc, st, L, solve_prev);
+        else      hipLaunchKernelGGL((k_register<false, kBigWaves>), dim3(nblocks), dim3(kBigWaves * 64), 0, h->stream, dc, st, L, solve_prev);
+    } else {
+        if (hook) hipLaunchKernelGGL((k_register<true, NW>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
+        else      hipLaunchKernelGGL((k_register<false, NW>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
+    }
+}
+
 void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* events, bool coarse = false)
 {
     const int n = h->prm.max_iter;
@@ -416,7 +433,7 @@ void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* eve
         const int slot = !coarse ? 2 * L : (L == 0 ? 0 : (L == 1 ? 2 : (L == n - 1 ? 6 : 4)));
         const bool open = events && (!coarse || L <= 2 || L == n - 1), close = events && (!coarse || L <= 1 || L >= n - 2);
         if (open) (void)hipEventRecord(events[slot], h->stream);
-        hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, (fuse && L >= 2) ? 1 : 0);
+        launch_register(h, false, nblocks, dc, st, L, (fuse && L >= 2) ? 1 : 0);
         if (close) (void)hipEventRecord(events[slot + 1], h->stream);
         if (!fuse || L == 0 || L == n - 1) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
     }
@@ -608,6 +625,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_NO_GRAPH")) h->use_graph = !(e[0] == '1');
     if (const char* e = getenv("S2M_NO_FUSE")) h->fuse_solve = !(e[0] == '1');
     if (const char* e = getenv("S2M_DENSITY_RAW")) h->density_raw = atoi(e);
+    if (const char* e = getenv("S2M_BIG_BLOCKS")) h->big_blocks = !(e[0] == '0');
     h->fuse_max_blocks = kFuseMaxBlocks;
     if (const char* e = getenv("S2M_FUSE_MAX")) h->fuse_max_blocks = atoi(e);
 
@@ -637,6 +655,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
 
     memset(&h->hctx, 0, sizeof(h->hctx));
     h->hctx.nblocks = kBlocksQuantum;
+    h->hctx.wpb = kBlock / 64;
     h->hctx.partials = h->partials.as<double>();
     h->hctx.state = h->state.as<DevState>();
     h->hctx.trace = h->trace.as<s2m_iter_trace>();
@@ -996,7 +1015,7 @@ int s2m_surf_optimization(s2m_handle h, const float pose[6], int32_t* idx5, floa
     h->ctx_dirty = true;
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
-    hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
+    launch_register(h, true, h->hctx.nblocks, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
     S2M_HIP(h, hipGetLastError());
     if (idx5) S2M_HIP(h, hipMemcpyAsync(idx5, h->dbg_idx5.p, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, h->stream));
     if (d2_5) S2M_HIP(h, hipMemcpyAsync(d2_5, h->dbg_d2.p, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, h->stream));
@@ -1013,7 +1032,7 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
     if (!h || !pose || !out || launches == 0) return S2M_ERR_INVALID_ARG;
     if (!h->have_scan || h->n_m == 0 || h->n_q == 0) return fail(h, S2M_ERR_NO_SCAN, "needs a resident scan and map");
     S2M_HIP(h, hipSetDevice(h->device));
-    const size_t nwaves = (size_t)h->hctx.nblocks * (kBlock / 64);   // one record per wave of the grid
+    const size_t nwaves = (size_t)h->hctx.nblocks * (size_t)h->hctx.wpb;   // one record per wave of the grid
     int rc;
     if ((rc = ensure(h, h->dbg_clk, sizeof(uint64_t) * kProfWords * nwaves))) return rc;
     S2M_HIP(h, hipMemsetAsync(h->dbg_clk.p, 0, sizeof(uint64_t) * kProfWords * nwaves, h->stream));
@@ -1034,13 +1053,13 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
         }
         h->hctx.density_pending = 0;                      // cleared on the device by the kernel: keep the host copy in step
         for (int L = 0; L < N; L++) {
-            hipLaunchKernelGGL(k_register<false>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, (fuse && L >= 2) ? 1 : 0);
+            launch_register(h, false, nblocks, dc, st, L, (fuse && L >= 2) ? 1 : 0);
             if (!fuse || L == 0) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
         }
-        hipLaunchKernelGGL(k_register<true>, dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, N, (fuse && N >= 2) ? 1 : 0);
+        launch_register(h, true, nblocks, dc, st, N, (fuse && N >= 2) ? 1 : 0);
     }
     for (int rep = 0; rep < launches; rep++)
-        hipLaunchKernelGGL(k_register<true>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
+        launch_register(h, true, h->hctx.nblocks, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
     S2M_HIP(h, hipGetLastError());
     const size_t n = nwaves < cap_waves ? nwaves : cap_waves;
     S2M_HIP(h, hipMemcpyAsync(out, h->dbg_clk.p, sizeof(uint64_t) * kProfWords * n, hipMemcpyDeviceToHost, h->stream));
@@ -1085,7 +1104,7 @@ int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6]
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
     const DevCtx* dc = h->dctx.as<DevCtx>();
-    hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, h->state.as<DevState>(), 0, 0);
+    launch_register(h, false, h->hctx.nblocks, dc, h->state.as<DevState>(), 0, 0);
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, h->state.as<DevState>(), 0, 1);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
@@ -1168,7 +1187,7 @@ int s2m_debug_time_steady(s2m_handle h, const float pose[6], int reps, int solve
     const int L = h->prm.max_iter;
     S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
     for (int k = 0; k < reps; k++)
-        hipLaunchKernelGGL(k_register<false>, dim3(h->hctx.nblocks), dim3(kBlock), 0, h->stream, dc, h->state.as<DevState>(), L, solve_prev ? 1 : 0);
+        launch_register(h, false, h->hctx.nblocks, dc, h->state.as<DevState>(), L, solve_prev ? 1 : 0);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));

@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restri
     const auto st = G(state);
     // loop state, fetched up front (the state block is a kernel argument: no pointer chase through DevCtx)
     const int done0 = st->done, degen0 = st->isDegenerate;
-    const int nb_act = (st->n_waves + (kBlock / 64) - 1) / (kBlock / 64);
+    const int nb_act = (st->n_waves + cp->wpb - 1) / cp->wpb;
     float pose0[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) pose0[k] = st->pose2[iter & 1][k];

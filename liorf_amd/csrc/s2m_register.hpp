@@ -972,10 +972,9 @@ __device__ __forceinline__ void linearise_chunk(const DevCtx* __restrict__ cp, c
     linearise_point<HOOK>(cp, T, sc6, i, px, py, pz, pl, acc);
 }
 
-template <bool HOOK>
-__global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int launch, int solve_prev)
+template <bool HOOK, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void k_register(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int launch, int solve_prev)
 {
-    constexpr int NW = kBlock / 64;
     // The loop state block never moves, so it comes as a kernel argument: `done` and the wave count arrive
     // with the first round trip, in parallel with the DevCtx block, instead of behind a pointer chase.
     const auto st = G(state);
@@ -1043,7 +1042,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_register(const DevCtx* __restrict
 #pragma unroll
             for (int k = 0; k < 6; k++) pose0[k] = st->pose2[(launch - 1) & 1][k];
             if (HOOK) lm_stamps[5] = wall_clock64();
-            const bool ended = lm_close_iteration<kBlock, false>(cp, st, nb_act, launch - 1, blockIdx.x == 0, false, pose0, degen0,
+            const bool ended = lm_close_iteration<NW * 64, false>(cp, st, nb_act, launch - 1, blockIdx.x == 0, false, pose0, degen0,
                                                                  sh, s_lm_out, pose, HOOK ? lm_stamps : nullptr);
             if (ended) return;
         } else {

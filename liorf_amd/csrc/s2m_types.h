@@ -15,6 +15,9 @@ constexpr int kProfWords = 32;         // uint64 words per wave written by the d
 constexpr int kBlocksQuantum = 8;      // graph cache key granularity (workgroups)
 constexpr int kNbrCap = 16;           // neighbourhood capacity per scan point (s2m_register.hpp: kNbr)
 constexpr int kMaxBlocks = 512;        // largest k_register grid: two 8-wave workgroups on each of the 256 CUs, all co-resident
+constexpr int kBigWaves = 16;          // a scan that needs more than one 8-wave workgroup per CU runs 16-wave workgroups, one per CU: every
+                                       // workgroup reads every row of partial sums when it closes an iteration, and rows x workgroups
+                                       // is 4x smaller with half as many workgroups
 
 // Uniform search grid over the map: cell edge E >= sqrt(gate_sq)*(1+2^-10), so the 3x3x3
 // neighbourhood of a query's cell holds every map point with fp32 d2 < gate_sq.
@@ -62,6 +65,7 @@ struct DevCtx {
     int32_t* nbr;                 // [kNbr][n_q] the neighbourhood: positions in map_sorted of EVERY map point within r_out of q_ref
     float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to the tuple; pa = NaN: this point contributes nothing
     int32_t n_q, n_m, nblocks;    // nblocks: workgroups of a k_register launch (<= kMaxBlocks; waves loop over the wave table)
+    int32_t wpb;                  // waves per workgroup of k_register for this scan: kBlock / 64 or kBigWaves
     int32_t table_cap;            // capacity of wave_table in entries
     const int2* wave_table;       // [table_cap] {first sorted point, count <= 64} per wave-table entry
     const int32_t* n_waves;       // entries of wave_table in use
