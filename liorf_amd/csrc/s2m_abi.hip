@@ -67,7 +67,7 @@ struct s2m_context {
 
     // pinned host staging
     DevState* h_state = nullptr;       // [2]: [0] upload, [1] download
-    s2m_iter_trace* h_trace = nullptr; // [kMaxIter]
+    s2m_iter_trace* h_trace = nullptr; // [kMaxIter], directly behind h_state[1]: state and trace come back in one copy
     uint32_t* h_mm = nullptr;          // [6]
     double* h_sc = nullptr;            // [1200 + 20]
 
@@ -362,7 +362,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     h->ctx_dirty = true;
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
     h->scan_timing_pending = true;
-    if ((rc = upload_ctx(h))) return rc;
+    // (the DevCtx block goes to the device with the next launch that needs it: upload_ctx / push_state)
     // A host source (pageable or pinned) has been copied by the time this returns; the ordering kernels behind the copy
     // keep running.  A device-resident source is read asynchronously and must outlive the next synchronising call.
     if (!on_device) S2M_HIP(h, hipEventSynchronize(h->ev_up));
@@ -384,8 +384,13 @@ int push_state(s2m_context* h, const float pose[6])
 {
     DevState s;
     fill_state(h, &s, pose);
-    hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, h->stream, h->state.as<DevState>(), s,
-                       (const int32_t*)h->n_waves.as<int32_t>());
+    if (h->ctx_dirty) {
+        hipLaunchKernelGGL(k_set_ctx_state, dim3(1), dim3(64), 0, h->stream, h->dctx.as<DevCtx>(), h->hctx, h->state.as<DevState>(), s,
+                           (const int32_t*)h->n_waves.as<int32_t>());
+        h->ctx_dirty = false;
+    } else
+        hipLaunchKernelGGL(k_set_state, dim3(1), dim3(64), 0, h->stream, h->state.as<DevState>(), s,
+                           (const int32_t*)h->n_waves.as<int32_t>());
     S2M_HIP(h, hipGetLastError());
     return S2M_OK;
 }
@@ -638,11 +643,12 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (hipEventCreate(&h->ev_a) != hipSuccess || hipEventCreate(&h->ev_b) != hipSuccess ||
         hipEventCreate(&h->ev_c) != hipSuccess || hipEventCreate(&h->ev_d) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess) return bail(S2M_ERR_HIP);
-    if (hipHostMalloc((void**)&h->h_state, sizeof(DevState) * 2) != hipSuccess) return bail(S2M_ERR_HIP);
-    if (hipHostMalloc((void**)&h->h_trace, sizeof(s2m_iter_trace) * kMaxIter) != hipSuccess) return bail(S2M_ERR_HIP);
+    static_assert(sizeof(DevState) % 8 == 0, "the trace follows the state block");
+    if (hipHostMalloc((void**)&h->h_state, sizeof(DevState) * 2 + sizeof(s2m_iter_trace) * kMaxIter) != hipSuccess) return bail(S2M_ERR_HIP);
+    h->h_trace = reinterpret_cast<s2m_iter_trace*>(h->h_state + 2);
     if (hipHostMalloc((void**)&h->h_mm, 64) != hipSuccess) return bail(S2M_ERR_HIP);
     if (hipHostMalloc((void**)&h->h_sc, sizeof(double) * 1220) != hipSuccess) return bail(S2M_ERR_HIP);
-    if (ensure(h, h->state, sizeof(DevState)) || ensure(h, h->trace, sizeof(s2m_iter_trace) * kMaxIter) ||
+    if (ensure(h, h->state, sizeof(DevState) + sizeof(s2m_iter_trace) * kMaxIter) ||      // loop state, then the trace
         ensure(h, h->dctx, sizeof(DevCtx)) || ensure(h, h->mm, 64) ||
         ensure(h, h->partials, sizeof(double) * 2 * kAcc * kBlocksQuantum) ||
         ensure(h, h->sc_bins, sizeof(uint32_t) * 1200) || ensure(h, h->sc_out, sizeof(double) * 1220) ||
@@ -658,7 +664,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->hctx.wpb = kBlock / 64;
     h->hctx.partials = h->partials.as<double>();
     h->hctx.state = h->state.as<DevState>();
-    h->hctx.trace = h->trace.as<s2m_iter_trace>();
+    h->hctx.trace = reinterpret_cast<s2m_iter_trace*>(h->state.as<DevState>() + 1);
     params_to_ctx(h, prm);
     if (const char* e = getenv("S2M_ABLATE")) h->hctx.ablate = atoi(e);
     h->ctx_dirty = true;
@@ -682,7 +688,7 @@ int s2m_destroy(s2m_handle h)
     for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
                        &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->npos, &h->nbr, &h->cert, &h->aux, &h->plane_cache, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of, &h->q_block_hist,
-                       &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->trace, &h->dctx, &h->mm,
+                       &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out,
                        &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds,
                        &h->sc_store_desc, &h->sc_store_ring, &h->sc_store_sector, &h->sc_cand, &h->sc_res };
@@ -692,7 +698,6 @@ int s2m_destroy(s2m_handle h)
     if (h->icp_src.p) (void)hipFree(h->icp_src.p);
     if (h->icp_tgt.p) (void)hipFree(h->icp_tgt.p);
     if (h->h_state) (void)hipHostFree(h->h_state);
-    if (h->h_trace) (void)hipHostFree(h->h_trace);
     if (h->h_mm) (void)hipHostFree(h->h_mm);
     if (h->h_sc) (void)hipHostFree(h->h_sc);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
@@ -753,12 +758,10 @@ int s2m_optimize_launch(s2m_handle h, const float pose[6])
     h->pending_skipped = 0;
     if (h->n_m == 0) { h->pending_skipped = 1; return S2M_OK; }                    // :1297
     if ((int)h->n_q <= h->prm.min_feats) { h->pending_skipped = 2; return S2M_OK; } // :1300
-    int rc = upload_ctx(h);
-    if (rc) return rc;
-    if ((rc = push_state(h, pose))) return rc;
+    int rc;
+    if ((rc = push_state(h, pose))) return rc;             // (with the DevCtx block when that changed)
     if ((rc = launch_loop(h))) return rc;
-    S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
-    S2M_HIP(h, hipMemcpyAsync(h->h_trace, h->trace.p, sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
+    S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
     return S2M_OK;
 }
 
@@ -944,8 +947,7 @@ int s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses)
         s2m_context* k = h->kids[(size_t)b];
         k->hctx.density_pending = 0;
         S2M_HIP(h, hipEventRecord(k->ev_a, h->stream)); S2M_HIP(h, hipEventRecord(k->ev_b, h->stream));     // (collect reads a per-handle time)
-        S2M_HIP(h, hipMemcpyAsync(&k->h_state[1], k->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
-        S2M_HIP(h, hipMemcpyAsync(k->h_trace, k->trace.p, sizeof(s2m_iter_trace) * k->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
+        S2M_HIP(h, hipMemcpyAsync(&k->h_state[1], k->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * k->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
     }
     return S2M_OK;
 }

@@ -1362,6 +1362,12 @@ __global__ __launch_bounds__(256) void k_debug_sincos(const float* __restrict__ 
 // keep a staging buffer alive or synchronise to update them.
 __global__ void k_set_ctx(DevCtx* dst, DevCtx v) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v; }
 // The wave count of the resident scan (left by k_chunk_table) is folded into the state block here.
+// the DevCtx block and the loop state of a scan in one launch (s2m_optimize: both change with every scan)
+__global__ void k_set_ctx_state(DevCtx* cdst, DevCtx c, DevState* dst, DevState v, const int32_t* n_waves)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { *cdst = c; v.n_waves = n_waves ? *n_waves : 0; *dst = v; }
+}
+
 __global__ void k_set_state(DevState* dst, DevState v, const int32_t* n_waves)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) { v.n_waves = n_waves ? *n_waves : 0; *dst = v; }

@@ -23,7 +23,9 @@ for mode in [m for m in os.environ.get("S2M_WAVES", "").split(",") if m]:
     eng.setScan(synth.to_xyzi(cfg["scan"]))
     L = int(mode[4:]) if mode.startswith("loop") else 0
     w = eng.wave_profile(cfg["pose_init"], launches=-(L + 1)).astype(np.int64)
-    w = w[w[:, 0] > 0]
+    widx = np.arange(len(w)) % 8                       # wave number inside its workgroup (8-wave shape)
+    keep = w[:, 0] > 0
+    w, widx = w[keep], widx[keep]
     t0 = w[:, 0].min()
     us = lambda a: a / 100.0
     close = us(np.where(w[:, 22] > 0, w[:, 22] - w[:, 0], 0))
@@ -39,6 +41,8 @@ for mode in [m for m in os.environ.get("S2M_WAVES", "").split(",") if m]:
             print("   %-11s waves: %5d (%.1f%%) associate med %.2f p99 %.2f max %.2f us; tile pts med %d max %d; searching lanes med %d" % (
                 nm, sel.sum(), 100.0 * sel.mean(), np.median(p1[sel]), np.percentile(p1[sel], 99), p1[sel].max(),
                 np.median(w[sel, 6]), w[sel, 6].max(), np.median(w[sel, 11])))
+    print("   by wave number in the workgroup (same SIMD: w and w+4): mean total " + " ".join("%.1f" % tot[widx == k].mean() for k in range(8)) +
+          "; mean tile pts " + " ".join("%.0f" % w[widx == k, 6].mean() for k in range(8)))
     srch = w[:, 12] > 0
     if srch.any():
         beg = np.maximum(w[:, 22], w[:, 0])
