@@ -87,7 +87,7 @@ struct s2m_context {
     unsigned long long map_epoch = 0;     // bumped by every s2m_set_map: children re-adopt the index when it changed
     unsigned long long adopted_epoch = 0;
 
-    std::map<int, hipGraphExec_t> graphs;
+    std::map<long long, hipGraphExec_t> graphs;
     std::vector<hipEvent_t> iter_events;
     bool use_graph = true;
     bool fuse_solve = true;            // env S2M_NO_FUSE=1 keeps one k_finalize per iteration (A/B measurements)
@@ -95,6 +95,9 @@ struct s2m_context {
     hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_d = nullptr, ev_up = nullptr;
     float t_optimize_ms = 0, t_set_map_ms = 0, t_set_scan_ms = 0;
     int base_parts = 1;
+    int  seg_iters = 8;                // with early exit on, the loop is issued as launches 0..seg-1 and, only if those did not converge, the rest (env S2M_SEGMENT, 0 = one piece)
+    bool seg_pending = false;          // the launch in flight was the first range only
+    hipEvent_t ev_a2 = nullptr, ev_b2 = nullptr;
     bool big_blocks = true;            // env S2M_BIG_BLOCKS=0: 8-wave workgroups whatever the scan size (A/B measurements)
     int density_raw = 320;             // box points above which a wave asks for a finer cut (env S2M_DENSITY_RAW, 0 = off)
     bool opt_pending = false;
@@ -422,38 +425,44 @@ inline void launch_register(s2m_context* h, bool hook, int nblocks, const DevCtx
     }
 }
 
-void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* events, bool coarse = false)
+// Launches L0 .. L1-1 of the loop.  A range that starts after launch 0 begins like launch 1 does (transform rebuilt from the
+// pose the k_finalize before it stored), and a range that ends before the last launch closes its last iteration with a
+// k_finalize of its own: with early exit on, the loop is issued in two ranges and the second only if the first did not converge.
+void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* events, bool coarse = false, int L0 = 0, int L1 = -1)
 {
     const int n = h->prm.max_iter;
+    if (L1 < 0) L1 = n;
     DevState* st = h->state.as<DevState>();
     const bool fuse = h->fuse_solve && nblocks <= h->fuse_max_blocks;
-    if (h->density_raw > 0) {
+    if (h->density_raw > 0 && L0 == 0) {
         // re-split the wave table for the map density at the initial guess (the transform k_set_state just stored);
         // both kernels take everything from the DevCtx block, so the captured graph stays valid from scan to scan
         hipLaunchKernelGGL(k_wave_density, dim3((h->hctx.table_cap + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
                            h->density_raw);
         hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, const_cast<DevCtx*>(dc), st);
     }
-    for (int L = 0; L < n; L++) {
+    for (int L = L0; L < L1; L++) {
         const int slot = !coarse ? 2 * L : (L == 0 ? 0 : (L == 1 ? 2 : (L == n - 1 ? 6 : 4)));
         const bool open = events && (!coarse || L <= 2 || L == n - 1), close = events && (!coarse || L <= 1 || L >= n - 2);
         if (open) (void)hipEventRecord(events[slot], h->stream);
-        launch_register(h, false, nblocks, dc, st, L, (fuse && L >= 2) ? 1 : 0);
+        launch_register(h, false, nblocks, dc, st, L, (fuse && L >= 2 && L != L0) ? 1 : 0);
         if (close) (void)hipEventRecord(events[slot + 1], h->stream);
-        if (!fuse || L == 0 || L == n - 1) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
+        if (!fuse || L == 0 || L == L1 - 1) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
     }
 }
 
-int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
+// part 0: the whole loop; 1: launches 0 .. seg-1; 2: launches seg .. max_iter-1
+int get_graph(s2m_context* h, int nblocks, int part, hipGraphExec_t* out)
 {
-    const int key = h->hctx.table_cap;                    // fixes both grids in the captured loop: k_register's (nblocks) and k_wave_density's
+    // table_cap fixes both grids in the captured loop: k_register's (nblocks) and k_wave_density's
+    const long long key = ((long long)h->hctx.table_cap * 4 + part) * 256 + (part ? h->seg_iters : 0);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { *out = it->second; return S2M_OK; }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     const DevCtx* dc = h->dctx.as<DevCtx>();
     S2M_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_loop(h, nblocks, dc, nullptr);
+    enqueue_loop(h, nblocks, dc, nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "hipStreamEndCapture", e);
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -464,26 +473,27 @@ int get_graph(s2m_context* h, int nblocks, hipGraphExec_t* out)
     return S2M_OK;
 }
 
-int launch_loop(s2m_context* h)
+int launch_loop(s2m_context* h, int part = 0)
 {
     const int nblocks = h->hctx.nblocks;
+    hipEvent_t e0 = part == 2 ? h->ev_a2 : h->ev_a, e1 = part == 2 ? h->ev_b2 : h->ev_b;
     if (h->use_graph) {
         hipGraphExec_t exec = nullptr;
-        int rc = get_graph(h, nblocks, &exec);
+        int rc = get_graph(h, nblocks, part, &exec);
         if (rc == S2M_OK) {
-            S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
+            S2M_HIP(h, hipEventRecord(e0, h->stream));
             S2M_HIP(h, hipGraphLaunch(exec, h->stream));
-            S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+            S2M_HIP(h, hipEventRecord(e1, h->stream));
             h->hctx.density_pending = 0;                  // cleared on the device by k_chunk_table_density: keep the host copy in step
             return S2M_OK;
         }
         h->use_graph = false;       // capture unsupported here: fall back to plain launches
     }
     const DevCtx* dc = h->dctx.as<DevCtx>();
-    S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
-    enqueue_loop(h, nblocks, dc, nullptr);
+    S2M_HIP(h, hipEventRecord(e0, h->stream));
+    enqueue_loop(h, nblocks, dc, nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
     S2M_HIP(h, hipGetLastError());
-    S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
+    S2M_HIP(h, hipEventRecord(e1, h->stream));
     h->hctx.density_pending = 0;
     return S2M_OK;
 }
@@ -631,6 +641,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_NO_FUSE")) h->fuse_solve = !(e[0] == '1');
     if (const char* e = getenv("S2M_DENSITY_RAW")) h->density_raw = atoi(e);
     if (const char* e = getenv("S2M_BIG_BLOCKS")) h->big_blocks = !(e[0] == '0');
+    if (const char* e = getenv("S2M_SEGMENT")) h->seg_iters = atoi(e);
     h->fuse_max_blocks = kFuseMaxBlocks;
     if (const char* e = getenv("S2M_FUSE_MAX")) h->fuse_max_blocks = atoi(e);
 
@@ -642,6 +653,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     }
     if (hipEventCreate(&h->ev_a) != hipSuccess || hipEventCreate(&h->ev_b) != hipSuccess ||
         hipEventCreate(&h->ev_c) != hipSuccess || hipEventCreate(&h->ev_d) != hipSuccess ||
+        hipEventCreate(&h->ev_a2) != hipSuccess || hipEventCreate(&h->ev_b2) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming) != hipSuccess) return bail(S2M_ERR_HIP);
     static_assert(sizeof(DevState) % 8 == 0, "the trace follows the state block");
     if (hipHostMalloc((void**)&h->h_state, sizeof(DevState) * 2 + sizeof(s2m_iter_trace) * kMaxIter) != hipSuccess) return bail(S2M_ERR_HIP);
@@ -702,6 +714,8 @@ int s2m_destroy(s2m_handle h)
     if (h->h_sc) (void)hipHostFree(h->h_sc);
     if (h->ev_a) (void)hipEventDestroy(h->ev_a);
     if (h->ev_b) (void)hipEventDestroy(h->ev_b);
+    if (h->ev_a2) (void)hipEventDestroy(h->ev_a2);
+    if (h->ev_b2) (void)hipEventDestroy(h->ev_b2);
     if (h->ev_c) (void)hipEventDestroy(h->ev_c);
     if (h->ev_d) (void)hipEventDestroy(h->ev_d);
     if (h->ev_up) (void)hipEventDestroy(h->ev_up);
@@ -760,7 +774,8 @@ int s2m_optimize_launch(s2m_handle h, const float pose[6])
     if ((int)h->n_q <= h->prm.min_feats) { h->pending_skipped = 2; return S2M_OK; } // :1300
     int rc;
     if ((rc = push_state(h, pose))) return rc;             // (with the DevCtx block when that changed)
-    if ((rc = launch_loop(h))) return rc;
+    h->seg_pending = h->prm.early_exit && h->seg_iters > 1 && h->seg_iters < h->prm.max_iter;
+    if ((rc = launch_loop(h, h->seg_pending ? 1 : 0))) return rc;
     S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
     return S2M_OK;
 }
@@ -780,6 +795,17 @@ int s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu, s
         S2M_HIP(h, hipSetDevice(h->device));
         S2M_HIP(h, hipStreamSynchronize(h->stream));
         S2M_HIP(h, hipEventElapsedTime(&h->t_optimize_ms, h->ev_a, h->ev_b));
+        if (h->seg_pending && !h->h_state[1].done) {
+            // the first range did not converge: the rest of the loop
+            int rc2 = launch_loop(h, 2);
+            if (rc2) return rc2;
+            S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
+            S2M_HIP(h, hipStreamSynchronize(h->stream));
+            float t2 = 0.0f;
+            S2M_HIP(h, hipEventElapsedTime(&t2, h->ev_a2, h->ev_b2));
+            h->t_optimize_ms += t2;
+        }
+        h->seg_pending = false;
         const DevState& s = h->h_state[1];
         memcpy(t, s.pose, 24);
         r.iters_run = s.iters_run; r.converged = s.converged; r.is_degenerate = s.isDegenerate;

@@ -128,3 +128,32 @@ def test_results_are_bitwise_reproducible(cfg_kitti64):
             assert np.array_equal(runs[k][j].view(np.uint32), runs[0][j].view(np.uint32)), (k, j)
     runs[0][0].close()
     runs[2][0].close()
+
+
+def test_loop_in_two_ranges_equals_the_loop_in_one_piece(monkeypatch):
+    """With early exit on the loop is issued as launches 0..seg-1 and, if those did not converge, the rest (s2m_abi.hip,
+    enqueue_loop).  A convergence threshold tight enough that the loop runs past the first range: same trace, bit for
+    bit, as the loop issued in one piece; and the default thresholds (converges inside the first range) as well."""
+    cfg = synth.make_config("small")
+    m, s = synth.to_xyzi(cfg["map"]), synth.to_xyzi(cfg["scan"])
+
+    def run(segment, **prm):
+        monkeypatch.setenv("S2M_SEGMENT", segment)
+        g = s2m.MapOptimizationS2M(early_exit=1, **prm)
+        g.setInputCloud(m)
+        r = g.optimize(s, cfg["pose_init"])
+        tr = g.trace()
+        out = (r.iters_run, r.converged, r.n_sel_last, np.array(r.pose, np.float32),
+               np.array([t.n_sel for t in tr]), np.array([t.pose[:] for t in tr], np.float32))
+        g.close()
+        return out
+
+    for prm, past_first in ((dict(conv_deg=0.0, conv_cm=0.0), True), (dict(), False)):
+        one = run("0", **prm)
+        for seg in ("8", "3"):
+            two = run(seg, **prm)
+            assert two[:3] == one[:3], (seg, two[:3], one[:3])
+            assert np.array_equal(two[4], one[4])
+            for k in (3, 5):
+                assert np.array_equal(two[k].view(np.uint32), one[k].view(np.uint32)), (seg, k)
+        assert (one[0] > 8) == past_first, one[0]          # (the tight thresholds take the loop past both first ranges)
