@@ -284,7 +284,10 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     const int table_cap = nblocks * NW;                   // wave-table entries: every chunk plus the budget for split chunks
     // more entries than one 8-wave workgroup per CU holds: 16-wave workgroups, one per CU (s2m_types.h, kBigWaves)
     const int wpb = (h->big_blocks && n_chunks * base_parts > (kMaxBlocks / 2) * NW) ? kBigWaves : NW;
-    nblocks = std::min((table_cap + wpb - 1) / wpb, kMaxBlocks * NW / wpb);   // the grid stays co-resident: waves loop over the table
+    // the grid stays co-resident - one workgroup per CU in either shape (the 8-wave shape of a single scan is built for 2 waves
+    // per SIMD: 256 registers per lane, no scratch; the scan slots of a batch run the 128-register build, two per CU) - and waves
+    // loop over the table
+    nblocks = std::min((table_cap + wpb - 1) / wpb, (wpb == NW && h->parent) ? kMaxBlocks : kMaxBlocks / 2);
     h->hctx.wpb = wpb;
     h->hctx.nblocks = nblocks;
     h->hctx.table_cap = table_cap;
@@ -417,11 +420,15 @@ inline void launch_register(s2m_context* h, bool hook, int nblocks, const DevCtx
 {
     constexpr int NW = kBlock / 64;
     if (h->hctx.wpb == kBigWaves) {
-        if (hook) hipLaunchKernelGGL((k_register<true, kBigWaves>), dim3(nblocks), dim3(kBigWaves * 64), 0, h->stream, dc, st, L, solve_prev);
-        else      hipLaunchKernelGGL((k_register<false, kBigWaves>), dim3(nblocks), dim3(kBigWaves * 64), 0, h->stream, dc, st, L, solve_prev);
+        if (hook) hipLaunchKernelGGL((k_register<true, kBigWaves, 4>), dim3(nblocks), dim3(kBigWaves * 64), 0, h->stream, dc, st, L, solve_prev);
+        else      hipLaunchKernelGGL((k_register<false, kBigWaves, 4>), dim3(nblocks), dim3(kBigWaves * 64), 0, h->stream, dc, st, L, solve_prev);
+    } else if (h->parent) {
+        // a scan slot of a batch: the 128-register build, so that two scans' workgroups share a CU
+        if (hook) hipLaunchKernelGGL((k_register<true, NW, 4>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
+        else      hipLaunchKernelGGL((k_register<false, NW, 4>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
     } else {
-        if (hook) hipLaunchKernelGGL((k_register<true, NW>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
-        else      hipLaunchKernelGGL((k_register<false, NW>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
+        if (hook) hipLaunchKernelGGL((k_register<true, NW, 2>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
+        else      hipLaunchKernelGGL((k_register<false, NW, 2>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
     }
 }
 

@@ -376,23 +376,9 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             }
         }
         const bool has_prior = searching && best.key[4] != kKeyInf;
-        const int nC = __popcll(cmask);
-        // wave bounding box of the searching lanes
-        const float mnx = wave_min_f32(searching ? sx : INFINITY), mxx = wave_max_f32(searching ? sx : -INFINITY);
-        const float mny = wave_min_f32(searching ? sy : INFINITY), mxy = wave_max_f32(searching ? sy : -INFINITY);
-        const float mnz = wave_min_f32(searching ? sz : INFINITY), mxz = wave_max_f32(searching ? sz : -INFINITY);
-
         const int cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
         const int cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
         const int cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
-        // cell_coord is monotone: the box of the lanes' cells is the cells of the box corners
-        const int bx0 = max(cell_coord(mnx, g.ox, g.inv_e, g.nx) - 1, 0), bx1 = min(cell_coord(mxx, g.ox, g.inv_e, g.nx) + 1, g.nx - 1);
-        const int by0 = max(cell_coord(mny, g.oy, g.inv_e, g.ny) - 1, 0), by1 = min(cell_coord(mxy, g.oy, g.inv_e, g.ny) + 1, g.ny - 1);
-        const int bz0 = max(cell_coord(mnz, g.oz, g.inv_e, g.nz) - 1, 0), bz1 = min(cell_coord(mxz, g.oz, g.inv_e, g.nz) + 1, g.nz - 1);
-        const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
-        const int R = nyb * nzb;                          // rows in the box
-        if (HOOK) { prof.rows = R; prof.why = 0; }
-
         // squared slab distances of this query to the faces of its own cell: lower bounds of the
         // distance to anything in the neighbouring row / cell on that side (see kSlabMargin)
         const float E = g.e;
@@ -410,24 +396,44 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         const bool tight = has_prior && sb < kTightBound;  // see the level layout of the tile path
         const float be = searching ? fminf(sb + (tight ? kNbrReach : kNbrReachCold), cover) : 0.0f;
         const float be2 = fmaxf(be * be, bound);          // rows / cells are selected with this; never tighter than the bound itself
-        const float rmax2 = wave_max_f32(searching ? be2 : 0.0f);
 
-        // ---- tile path: per group of 64 box rows, mark the rows some lane still needs, size them
-        // and stream them through the filter into the tile; the lanes are served one by one if the tile overflows.
-        // A box far larger than the lanes' own neighbourhoods (scattered points) is not worth staging, and neither is
-        // a tile for a handful of lanes.
+        // ---- tile passes.  A pass takes the first `group` searching lanes that are still to do: the box rows those lanes need
+        // are sized and streamed through a filter into the wave's LDS tile, and the lanes are settled from the tile.  A box far
+        // larger than the lanes' own neighbourhoods (scattered points) is not worth staging, and neither is a tile for a
+        // handful of lanes: those are served one by one below.  When the tile of a pass would overflow (a dense part of the
+        // map under a wide wave), the pass is repeated with half the lanes - consecutive lanes are neighbours in space, so
+        // the box and with it the tile shrink - instead of serving all of them one by one.
+        unsigned long long todo = cmask, pend = 0ull;
+        int group = 64;
+        while (todo) {
+        const bool act = ((todo >> lane) & 1ull) != 0ull && __popcll(todo & ((1ull << lane) - 1ull)) < group;
+        const unsigned long long amask = __ballot(act);
+        const int nA = __popcll(amask);
+        // bounding box of the pass's lanes
+        const float mnx = wave_min_f32(act ? sx : INFINITY), mxx = wave_max_f32(act ? sx : -INFINITY);
+        const float mny = wave_min_f32(act ? sy : INFINITY), mxy = wave_max_f32(act ? sy : -INFINITY);
+        const float mnz = wave_min_f32(act ? sz : INFINITY), mxz = wave_max_f32(act ? sz : -INFINITY);
+        // cell_coord is monotone: the box of the lanes' cells is the cells of the box corners
+        const int bx0 = max(cell_coord(mnx, g.ox, g.inv_e, g.nx) - 1, 0), bx1 = min(cell_coord(mxx, g.ox, g.inv_e, g.nx) + 1, g.nx - 1);
+        const int by0 = max(cell_coord(mny, g.oy, g.inv_e, g.ny) - 1, 0), by1 = min(cell_coord(mxy, g.oy, g.inv_e, g.ny) + 1, g.ny - 1);
+        const int bz0 = max(cell_coord(mnz, g.oz, g.inv_e, g.nz) - 1, 0), bz1 = min(cell_coord(mxz, g.oz, g.inv_e, g.nz) + 1, g.nz - 1);
+        const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
+        const int R = nyb * nzb;                          // rows in the box
+        if (HOOK) { prof.rows = R; prof.why = 0; }
+        const float rmax2 = wave_max_f32(act ? be2 : 0.0f);
         const int tile_cap = kTilePts;
         const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
         const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
         // (a short wave - 8, 16 or 32 points of a split chunk - whose lanes all search stages its tile and shares the sweeps)
-        const bool all_of_short = chunk.y <= 32 && cmask == ((1ull << chunk.y) - 1ull);
-        bool tile = !(ablate & 64) && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * max(nC, 8) && (nC > kServeLanes || all_of_short || (ablate & 128));
+        const bool all_of_short = chunk.y <= 32 && amask == ((1ull << chunk.y) - 1ull);
+        const bool few = nA <= kServeLanes && !all_of_short && !(ablate & 128);      // a handful of lanes: served
+        bool tile = !(ablate & 64) && !few && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * max(nA, 8);
         if (HOOK && !tile) prof.why = 1;
         int nt = 0;                                       // tile fill, wave-uniform
         for (int rg = 0; rg < R && tile; rg += 64) {
             // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
             unsigned long long want = 0ull;
-            if (searching) {
+            if (act) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
                     const int dyc = run_dy(k), dzc = run_dz(k);
@@ -488,7 +494,14 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         }
 
         if (HOOK) prof.ts[1] = wall_clock64();
-        if (tile) {
+        if (!tile) {
+            // too dense or too scattered for one tile: again with half the lanes, or - 16 lanes or fewer - served one by one
+            if (!few && nA > 16 && !(ablate & 64)) { group = (nA > 32) ? 32 : 16; continue; }
+            pend |= amask; todo &= ~amask;
+            continue;
+        }
+        todo &= ~amask;
+        {
             wave_lds_sync();
             if (HOOK) { prof.mode = 1; prof.pts = nt; }
             // The radii (squared) the tile points are counted against, widest first.  With a tuple to start from: from the
@@ -512,20 +525,20 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             // cut into kq parts of nslot = 64 / kq lanes, lane l works for slot l % nslot - the searching lane of that rank -
             // and sweeps every kq-th tile point; counts, lists and the rim are combined across the parts, and the searching
             // lane of rank r picks its result up from lane r (part 0 of its slot).  kq = 1: every lane works for itself.
-            const int kq = (nt <= 16 || nC > 32) ? 1 : ((nC > 16) ? 2 : ((nC > 8) ? 4 : 8));
+            const int kq = (nt <= 16 || nA > 32) ? 1 : ((nA > 16) ? 2 : ((nA > 8) ? 4 : 8));
             const int nslot = 64 / kq, part = lane / nslot;
             int own = lane;                                   // the searching lane this lane works for
             int col = lane;                                   // the lane whose results (and LDS column) are mine: my rank among the searching lanes
-            bool q_search = searching;
+            bool q_search = act;
             if (kq > 1) {
                 int* lown = reinterpret_cast<int*>(lrows);    // (the row table is not needed any more)
-                const int rank = __popcll(cmask & ((1ull << lane) - 1ull));
-                if (searching) lown[rank] = lane;
+                const int rank = __popcll(amask & ((1ull << lane) - 1ull));
+                if (act) lown[rank] = lane;
                 wave_lds_sync();
                 const int s_ = lane & (nslot - 1);
-                q_search = s_ < nC;
+                q_search = s_ < nA;
                 own = q_search ? lown[s_] : lane;
-                col = searching ? rank : lane;
+                col = act ? rank : lane;
             }
             float qx_ = sx, qy_ = sy, qz_ = sz;
             float ql_[kLevels];
@@ -594,7 +607,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                     mo = fminf(mo, (d > lvl2) ? d : INFINITY);
                 }
             }
-            bool fallback = searching && q_fallback;
+            bool fallback = act && q_fallback;
             if (kq > 1) {
                 // the lists of a slot's parts go into the column of its part 0, where the searching lane finds them
                 wave_lds_sync();
@@ -610,9 +623,9 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 mo = __shfl(mo, col, 64);
                 lvl2 = __shfl(lvl2, col, 64);
                 const int fb_col = __shfl((int)q_fallback, col, 64);       // (not inside a && / ?: - every lane has to take part in a shuffle)
-                fallback = searching & (fb_col != 0);
+                fallback = act & (fb_col != 0);
             }
-            const bool lister = searching && !fallback;
+            const bool lister = act && !fallback;
             if (HOOK) { prof.n_fb = __popcll(__ballot(fallback)); prof.reach_mm = (int)(rr * 1000.0f); prof.kq = kq; }
             if (!lister) cc = 0;
             wave_lds_sync();
@@ -679,13 +692,10 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 }
             }
         }
-        // ---- serve: the whole wave works for one searching lane at a time.  Lanes 0..8 size the lane's (<= 9) x-runs, the
-        // candidates (all map points of those cells) are read 64 at a time, their keys kept in the wave's LDS area, and seven
-        // rounds of "smallest key above the last one" pick the six nearest and the distance of the seventh: the lane's new
-        // neighbourhood and its radius.  ~2 dependent round trips per served lane.
+        }   // tile passes
         if (HOOK) prof.ts[2] = wall_clock64();
-        unsigned long long pend = (tile || nC > kWalkLanes) ? 0ull : cmask;
-        unsigned long long walk = (!tile && nC > kWalkLanes) ? cmask : 0ull;      // lanes that walk their own cells (below)
+        unsigned long long walk = 0ull;                   // lanes that walk their own cells (below)
+        if (__popcll(pend) > kWalkLanes) { walk = pend; pend = 0ull; }
         if (pend) {
             if (HOOK) prof.mode = (prof.why >= 2) ? 3 : 2;
             uint64_t* lkeys = reinterpret_cast<uint64_t*>(lpts);
@@ -972,8 +982,11 @@ __device__ __forceinline__ void linearise_chunk(const DevCtx* __restrict__ cp, c
     linearise_point<HOOK>(cp, T, sc6, i, px, py, pz, pl, acc);
 }
 
-template <bool HOOK, int NW>
-__global__ __launch_bounds__(NW * 64, 4) void k_register(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int launch, int solve_prev)
+// NW waves per workgroup; MINW waves per SIMD the kernel is built for: 2 (256 registers per lane, no scratch: a single scan up to
+// 2 048 waves has one 8-wave workgroup per CU anyway) or 4 (128 registers: two 8-wave workgroups per CU for batches of scans, or
+// one 16-wave workgroup for large scans)
+template <bool HOOK, int NW, int MINW>
+__global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int launch, int solve_prev)
 {
     // The loop state block never moves, so it comes as a kernel argument: `done` and the wave count arrive
     // with the first round trip, in parallel with the DevCtx block, instead of behind a pointer chase.
@@ -1084,7 +1097,15 @@ __global__ __launch_bounds__(NW * 64, 4) void k_register(const DevCtx* __restric
             if (HOOK || __ballot(need)) {
                 associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
                                       px, py, pz, cert, prof);
-                if (valid0) plane0 = G((const v4f*)cp->plane_cache)[chunk.x + lane];
+                // The point is read again (L2-warm) rather than kept in registers through the association: what the
+                // certified path holds in registers must not be live across the search, or the allocator spills it on
+                // the common path (measured: +1.1 us on every steady launch).
+                asm volatile("" ::: "memory");
+                if (valid0) {
+                    const int i = chunk.x + lane;
+                    px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];
+                    plane0 = G((const v4f*)cp->plane_cache)[i];
+                }
             }
             if (HOOK) clk1 = wall_clock64();
 #pragma unroll

@@ -17,7 +17,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libliorf_s2m.so")
+LIB_PATH = os.environ.get("S2M_LIB") or os.path.join(_HERE, "libliorf_s2m.so")   # S2M_LIB: A/B measurements of two builds
 
 S2M_OK = 0
 ERRORS = {-1: "S2M_ERR_INVALID_ARG", -2: "S2M_ERR_NO_DEVICE", -3: "S2M_ERR_HIP", -4: "S2M_ERR_NO_SCAN",
