@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
     WaveProf prof;
     double acc[kAcc];                                       // zeroed only after the association: nothing of pass 2 is live during pass 1
     const bool single = e0 + estride >= n_waves;            // one entry for this wave (every scan up to 262 144 points): its point stays in registers
-    if (single) {
+    if (__builtin_expect(single, 1)) {
         if (e0 < n_waves) {
             // the certificate test of associate_chunk, up front: a fully certified entry goes straight to its residuals
             const float sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
@@ -1094,7 +1094,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
             const float ex = sx - cert.x, ey = sy - cert.y, ez = sz - cert.z;
             const float eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
             const bool need = fin && !(!(ablate & 1) && (eps < cert.w));
-            if (HOOK || __ballot(need)) {
+            if (HOOK || __builtin_expect(__ballot(need) != 0ull, 0)) {     // (unlikely: the search is laid out away from the certified path)
                 associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
                                       px, py, pz, cert, prof);
                 // The point is read again (L2-warm) rather than kept in registers through the association: what the
@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
         }
     }
     // ---- pass 1: associate
-    if (any_need)
+    if (__builtin_expect(any_need, 0))
     for (int e = e0; e < n_waves; e += estride) {
         if (e != e0) {
             chunk = make_int2(__builtin_amdgcn_readfirstlane(tb[e].x), __builtin_amdgcn_readfirstlane(tb[e].y));
