@@ -210,11 +210,14 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     int ost = 0, nb_n = 0;
     float r_out = 0.0f, r7o = 0.0f;                      // r7o: every map point other than the first six members was at least this far from q_ref
     int opos[5] = { 0, 0, 0, 0, 0 };
-    if (lookB) {
+    int nfront[6] = { 0, 0, 0, 0, 0, 0 };                // the six front members of the neighbourhood, requested in the same round trip
+    if (lookB) {                                          // (meaningful only if the state word says the neighbourhood is valid)
         const v4i a = auxp[i];
-        r_out = __int_as_float(a.x); ost = a.y; nb_n = min(max(a.z, 0), kNbr); r7o = __int_as_float(a.w);
 #pragma unroll
         for (int j = 0; j < 5; j++) opos[j] = nposp[(size_t)j * nq + i];
+#pragma unroll
+        for (int j = 0; j < 6; j++) nfront[j] = nbrp[(size_t)j * nq + i];
+        r_out = __int_as_float(a.x); ost = a.y; nb_n = min(max(a.z, 0), kNbr); r7o = __int_as_float(a.w);
     }
     const bool had5 = lookB && (ost & 4) != 0;
     bool nbr_ok = lookB && (ost & 8) != 0;                // the stored neighbourhood holds every map point within r_out of q_ref (possibly none)
@@ -260,7 +263,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             {
                 int (&np_)[6] = np6;
 #pragma unroll
-                for (int k = 0; k < 6; k++) { np_[k] = 0; if (ev && k < nb_n) np_[k] = nbrp[(size_t)k * nq + i]; }
+                for (int k = 0; k < 6; k++) np_[k] = (ev && k < nb_n) ? nfront[k] : 0;
                 v3f mm[6];
 #pragma unroll
                 for (int k = 0; k < 6; k++) mm[k] = *reinterpret_cast<gptr<const v3f>>(&map[np_[k]]);
@@ -818,15 +821,24 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     bool changed = !had5;
 #pragma unroll
     for (int k = 0; k < 5; k++) changed = changed || ((int)key_lo(fk[k]) != opos[k]);
-    // coordinates + original indices of the six nearest (L2-warm)
+    bool tie_adj = false;                                 // equal distances among the six: the reference order is (d2, ORIGINAL index)
+#pragma unroll
+    for (int k = 0; k < 5; k++) tie_adj = tie_adj || (key_hi(fk[k]) == key_hi(fk[k + 1]) && key_hi(fk[k]) < 0x7f800000u);
+    tie_adj = tie_adj && upd;
+    // Coordinates + original indices of the six nearest (L2-warm) - only where they are needed: the plane has to be fitted
+    // (new tuple, or a tuple that was not gated before), or equal distances have to be put in index order.  A lane that
+    // re-measured and found its tuple unchanged (the lanes that do so in every launch of the steady state: near-ties
+    // between two of their neighbour distances leave them no slack) keeps its plane and skips the round trip.
+    const bool fetch6 = upd && (HOOK || changed || tie_adj || (ablate & 32) != 0 ||
+                                (complete && ((double)__uint_as_float(key_hi(fk[4])) < cp->gate_sq) && (ost & 3) == 0));
     v4f nb[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) nb[k] = map[(upd && key_hi(fk[k]) < 0x7f800000u) ? (int)key_lo(fk[k]) : 0];
-    {   // equal distances: the reference order is (d2, ORIGINAL index)
-        bool tie_adj = false;
+    for (int k = 0; k < 6; k++) nb[k] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+    if (__ballot(fetch6)) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) tie_adj = tie_adj || (key_hi(fk[k]) == key_hi(fk[k + 1]) && key_hi(fk[k]) < 0x7f800000u);
-        tie_adj = tie_adj && upd;
+        for (int k = 0; k < 6; k++) nb[k] = map[(fetch6 && key_hi(fk[k]) < 0x7f800000u) ? (int)key_lo(fk[k]) : 0];
+    }
+    {
         if (__ballot(tie_adj)) {
             if (tie_adj) {
 #pragma unroll

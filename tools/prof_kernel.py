@@ -43,6 +43,11 @@ for mode in [m for m in os.environ.get("S2M_WAVES", "").split(",") if m]:
                 np.median(w[sel, 6]), w[sel, 6].max(), np.median(w[sel, 11])))
     print("   by wave number in the workgroup (same SIMD: w and w+4): mean total " + " ".join("%.1f" % tot[widx == k].mean() for k in range(8)) +
           "; mean tile pts " + " ".join("%.0f" % w[widx == k, 6].mean() for k in range(8)))
+    for nm, sel in (("all lanes certified", (w[:, 9] == 0) & (w[:, 11] == 0)), ("some lanes re-measured, none searched", (w[:, 9] > 0) & (w[:, 11] == 0)),
+                    ("some lanes searched", w[:, 11] > 0)):
+        if sel.any():
+            print("   waves with %-38s %5d: total med %.2f p99 %.2f max %.2f us; associate med %.2f max %.2f us" % (
+                nm + ":", sel.sum(), np.median(tot[sel]), np.percentile(tot[sel], 99), tot[sel].max(), np.median(p1[sel]), p1[sel].max()))
     srch = w[:, 12] > 0
     if srch.any():
         beg = np.maximum(w[:, 22], w[:, 0])
