@@ -1124,11 +1124,16 @@ struct LmShared {
 // updated pose in pose_out and whether the loop has ended (converged with early exit on, or fewer
 // than min_corr correspondences).  kFull adds the iteration-0 degeneracy analysis on wave 1.
 // `writer` records the outcome in DevState / trace.  ne_only = normal equations only (observation hook).
-template <int NT, bool kFull>
+// `early` / `late`: work of the caller that does not depend on the pose and hides behind the serial part - called by every
+// thread once the partial sums are in (everything requested before the call has arrived by then), and again just before
+// the last barrier (wave 0: after the solve; the other waves: at once, they would only wait there).
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <int NT, bool kFull, typename Early = NoHook, typename Late = NoHook>
 __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp, gptr<DevState> st, int nb_act, int iter,
                                                    bool writer, bool ne_only, const float (&pose0)[6], int degen0,
                                                    LmShared& sh, float* s_out, float (&pose_out)[6],
-                                                   unsigned long long* stamps = nullptr)     // diagnostics: 5 wall-clock stamps
+                                                   unsigned long long* stamps = nullptr,     // diagnostics: 5 wall-clock stamps
+                                                   Early early = Early(), Late late = Late())
 {
     constexpr int NG = NT / 32;                         // row groups
     const auto trace = G(cp->trace);
@@ -1149,6 +1154,7 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
     sh.part[grp][col] = s;
     __syncthreads();
     if (stamps) stamps[0] = wall_clock64();
+    early();
 
     int n_sel = 0;
     if (wave == 0) {
@@ -1267,6 +1273,7 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
         }
     }
     if (stamps) stamps[3] = wall_clock64();
+    late();
     __syncthreads();
     if (stamps) stamps[4] = wall_clock64();
 #pragma unroll

@@ -61,6 +61,7 @@ constexpr float kNbrReachCold = 0.10f; // ... and beyond the gate when it has no
 constexpr int   kWalkLanes = 64;       // a wave whose tile overflowed serves up to this many lanes one by one; beyond, every lane walks its own cells
 constexpr int   kNbr = kNbrCap;        // neighbourhood capacity (map positions per scan point)
 constexpr int   kLevels = 6;           // radii a search counts against at once
+constexpr float kFragileSlack = 1e-4f; // a certificate with less slack than this may well fail in the steady state of the loop: such a lane prefetches
 constexpr int   kServeLanes = 4;       // up to this many searching lanes are served one by one instead of staging a tile
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));
@@ -172,6 +173,16 @@ struct WaveProf {
 // ------------------------------------------------------------------------------------------
 // pass 1: bring tuple / plane / certificate of the points of one wave-table entry up to date
 // ------------------------------------------------------------------------------------------
+// What a lane without slack needs to re-measure its six front members, requested by k_register while the previous
+// iteration is being closed (none of it depends on the pose).  `on`: this lane's copy is valid.
+struct Fragile {
+    bool on = false;
+    v4i aux = { 0, 0, 0, 0 };
+    int opos[5] = { 0, 0, 0, 0, 0 };
+    int front[6] = { 0, 0, 0, 0, 0, 0 };
+    v3f mm[6];
+};
+
 template <bool HOOK>
 __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, const GridDesc& g, gptr<const v4f> map,
                                                 gptr<const int32_t> cell_start, const float (&T)[12], float gatef, int ablate,
@@ -1051,6 +1062,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
     // from the host (libm); later launches rebuild them from the pose: lanes 0..2 take one angle each
     // (glibc's sinf / cosf arithmetic, see glibc_sincosf).  With solve_prev the pose is first advanced by closing
     // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.
+    Fragile frag;
+#pragma unroll
+    for (int k = 0; k < 6; k++) frag.mm[k] = v3f{ 0.0f, 0.0f, 0.0f };
     float T[12], sc6[6];
     if (!solve_prev && st->T_valid) {
 #pragma unroll
@@ -1067,8 +1081,28 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
 #pragma unroll
             for (int k = 0; k < 6; k++) pose0[k] = st->pose2[(launch - 1) & 1][k];
             if (HOOK) lm_stamps[5] = wall_clock64();
+            // lanes whose certificate leaves (next to) no slack fetch what their re-measurement needs behind the close
+            auto early = [&]() {
+                if (!HOOK && MINW == 2 && valid0 && !(cert.w > kFragileSlack) && !(ablate & 3)) {
+                    const int i = chunk.x + lane;
+                    frag.on = true;
+                    frag.aux = G((const v4i*)cp->aux)[i];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) frag.opos[j] = G(cp->npos)[(size_t)j * nq + i];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) frag.front[j] = G(cp->nbr)[(size_t)j * nq + i];
+                }
+            };
+            auto late = [&]() {
+                if (frag.on) {
+                    const bool ok = (frag.aux.y & 8) != 0;
+                    const int n = min(max(frag.aux.z, 0), kNbr);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) frag.mm[k] = *reinterpret_cast<gptr<const v3f>>(&map[(ok && k < n) ? frag.front[k] : 0]);
+                }
+            };
             const bool ended = lm_close_iteration<NW * 64, false>(cp, st, nb_act, launch - 1, blockIdx.x == 0, false, pose0, degen0,
-                                                                 sh, s_lm_out, pose, HOOK ? lm_stamps : nullptr);
+                                                                 sh, s_lm_out, pose, HOOK ? lm_stamps : nullptr, early, late);
             if (ended) return;
         } else {
 #pragma unroll
@@ -1106,7 +1140,80 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
             const float ex = sx - cert.x, ey = sy - cert.y, ez = sz - cert.z;
             const float eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
             const bool need = fin && !(!(ablate & 1) && (eps < cert.w));
-            if (HOOK || __builtin_expect(__ballot(need) != 0ull, 0)) {     // (unlikely: the search is laid out away from the certified path)
+            // Lanes without slack (a near-tie between two neighbour distances) fail that test in every launch, however small the
+            // step, and the wave that holds one would go through the association - a long way off in the instruction stream -
+            // while every other wave of the launch is done.  What such a lane needs has been fetched behind the close (frag):
+            // its six front members are measured right here.  If they prove the five nearest (tier B's argument against the
+            // unchanged reference position: gated, the 5th nearer than anything outside the six can be, no equal distances),
+            // the lane is settled on this path: tuple in the stored order - nothing to do; order changed - the plane is fitted
+            // again and tuple, plane and a certificate without slack are stored.  Any lane that cannot be settled this way
+            // sends the wave through the association as before.
+            bool quick = false;
+            if (!HOOK && MINW == 2 && __ballot(need) != 0ull) {
+                bool okl = true, flip = false;
+                Top6k t;
+#pragma unroll
+                for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
+                if (need) {
+                    okl = frag.on && (frag.aux.y & 12) == 12 && (frag.aux.y & 3) != 0;    // tuple complete, neighbourhood valid, plane known
+                    const int n = min(max(frag.aux.z, 0), kNbr);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const float dx = sx - frag.mm[k].x, dy = sy - frag.mm[k].y, dz = sz - frag.mm[k].z;
+                        const float d2 = (dx * dx + dy * dy) + dz * dz;                 // L2_Simple order
+                        top6k_insert(t, (okl && k < n) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)frag.front[k]) : kKeyInf);
+                    }
+                    const float r = __int_as_float(frag.aux.w) - eps;                   // everything outside the six is at least this far away
+                    const float d2_5 = __uint_as_float(key_hi(t.key[4]));
+                    okl = okl && key_hi(t.key[4]) < 0x7f800000u && ((double)d2_5 < cp->gate_sq) && (sqrtf(d2_5) + kCertMargin < r);
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        okl = okl && key_hi(t.key[k]) != key_hi(t.key[k + 1]);
+                        flip = flip || (int)key_lo(t.key[k]) != frag.opos[k];
+                    }
+                }
+                quick = __ballot(need && !okl) == 0ull;
+                flip = flip && need && quick;
+                if (__ballot(flip)) {
+                    if (flip) {
+                        const int i = chunk.x + lane;
+                        float qr[5][3], mx[5][3];
+#pragma unroll
+                        for (int j = 0; j < 5; j++) {                                   // the five nearest, in order (:1099-1101)
+                            float x = 0.0f, y = 0.0f, z = 0.0f;
+#pragma unroll
+                            for (int k = 0; k < 6; k++) {
+                                const bool is = frag.front[k] == (int)key_lo(t.key[j]);
+                                x = is ? frag.mm[k].x : x; y = is ? frag.mm[k].y : y; z = is ? frag.mm[k].z : z;
+                            }
+                            qr[j][0] = x; qr[j][1] = y; qr[j][2] = z; mx[j][0] = x; mx[j][1] = y; mx[j][2] = z;
+                        }
+                        float X[3];
+                        plane_fit_5x3(qr, X);                                           // :1104
+                        float pa = X[0], pb = X[1], pc = X[2], pd = 1.0f;
+                        const float ps = sqrtf(pa * pa + pb * pb + pc * pc);             // :1111
+                        pa /= ps; pb /= ps; pc /= ps; pd /= ps;
+                        bool planeValid = true;
+#pragma unroll
+                        for (int j = 0; j < 5; j++) {                                   // :1115-1122
+                            const float rr_ = pa * mx[j][0] + pb * mx[j][1] + pc * mx[j][2] + pd;
+                            if ((double)fabsf(rr_) > cp->plane_tol) planeValid = false;
+                        }
+                        const v4f pl = { planeValid ? pa : NAN, pb, pc, pd };
+                        G((v4f*)cp->plane_cache)[i] = pl;
+                        plane0 = pl;
+#pragma unroll
+                        for (int k = 0; k < 5; k++) G(cp->npos)[(size_t)k * nq + i] = (int)key_lo(t.key[k]);
+                        // the stored certificate spoke of the old order: none from now on (the reference position and the radii the
+                        // neighbourhood vouches for stay as they are)
+                        const v4f cnew = { cert.x, cert.y, cert.z, 0.0f };
+                        G((v4f*)cp->cert)[i] = cnew;
+                        const v4i anew = { frag.aux.x, (frag.aux.y & ~3) | (planeValid ? 1 : 2), frag.aux.z, frag.aux.w };
+                        G((v4i*)cp->aux)[i] = anew;
+                    }
+                }
+            }
+            if (HOOK || __builtin_expect(__ballot(need) != 0ull && !quick, 0)) {     // (unlikely: the search is laid out away from the certified path)
                 associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
                                       px, py, pz, cert, prof);
                 // The point is read again (L2-warm) rather than kept in registers through the association: what the
