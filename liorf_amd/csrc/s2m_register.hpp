@@ -1083,7 +1083,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
             if (HOOK) lm_stamps[5] = wall_clock64();
             // lanes whose certificate leaves (next to) no slack fetch what their re-measurement needs behind the close
             auto early = [&]() {
-                if (!HOOK && MINW == 2 && valid0 && !(cert.w > kFragileSlack) && !(ablate & 3)) {
+                if (!HOOK && valid0 && !(cert.w > kFragileSlack) && !(ablate & 3)) {
                     const int i = chunk.x + lane;
                     frag.on = true;
                     frag.aux = G((const v4i*)cp->aux)[i];
@@ -1149,19 +1149,19 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
             // again and tuple, plane and a certificate without slack are stored.  Any lane that cannot be settled this way
             // sends the wave through the association as before.
             bool quick = false;
-            if (!HOOK && MINW == 2 && __ballot(need) != 0ull) {
+            if (!HOOK && __ballot(need) != 0ull) {
                 bool okl = true, flip = false;
+                const int nfr = min(max(frag.aux.z, 0), kNbr);                          // members of the lane's neighbourhood
                 Top6k t;
 #pragma unroll
                 for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
                 if (need) {
                     okl = frag.on && (frag.aux.y & 12) == 12 && (frag.aux.y & 3) != 0;    // tuple complete, neighbourhood valid, plane known
-                    const int n = min(max(frag.aux.z, 0), kNbr);
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
                         const float dx = sx - frag.mm[k].x, dy = sy - frag.mm[k].y, dz = sz - frag.mm[k].z;
                         const float d2 = (dx * dx + dy * dy) + dz * dz;                 // L2_Simple order
-                        top6k_insert(t, (okl && k < n) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)frag.front[k]) : kKeyInf);
+                        top6k_insert(t, (okl && k < nfr) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)frag.front[k]) : kKeyInf);
                     }
                     const float r = __int_as_float(frag.aux.w) - eps;                   // everything outside the six is at least this far away
                     const float d2_5 = __uint_as_float(key_hi(t.key[4]));
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
                             float x = 0.0f, y = 0.0f, z = 0.0f;
 #pragma unroll
                             for (int k = 0; k < 6; k++) {
-                                const bool is = frag.front[k] == (int)key_lo(t.key[j]);
+                                const bool is = k < nfr && frag.front[k] == (int)key_lo(t.key[j]);   // (rows beyond the member count hold stale positions)
                                 x = is ? frag.mm[k].x : x; y = is ? frag.mm[k].y : y; z = is ? frag.mm[k].z : z;
                             }
                             qr[j][0] = x; qr[j][1] = y; qr[j][2] = z; mx[j][0] = x; mx[j][1] = y; mx[j][2] = z;

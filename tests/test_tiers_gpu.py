@@ -157,3 +157,36 @@ def test_loop_in_two_ranges_equals_the_loop_in_one_piece(monkeypatch):
             for k in (3, 5):
                 assert np.array_equal(two[k].view(np.uint32), one[k].view(np.uint32)), (seg, k)
         assert (one[0] > 8) == past_first, one[0]          # (the tight thresholds take the loop past both first ranges)
+
+
+def test_reused_handle_gives_bitwise_the_loop_of_a_fresh_one_that_searches_everything(monkeypatch):
+    """Per-point state of earlier scans (tuples, neighbourhoods, planes) stays in the handle's buffers; only the state
+    words are reset by s2m_set_scan.  Rows of a neighbourhood beyond its member count hold stale map positions - a
+    path that matched against them (the in-line re-measurement did, once) gives results that depend on what ran before.
+    A handle that has registered other scans against other maps must produce, bit for bit, the trace of a fresh
+    handle with certificates and re-measuring switched off."""
+    small, tiny = synth.make_config("small"), synth.make_config("tiny")
+    poses = [small["pose_init"], (small["pose_init"] + np.float32(0.01)).astype(np.float32),
+             (small["pose_init"] + np.array([0.002, -0.001, 0.004, 0.05, -0.03, 0.02], np.float32)).astype(np.float32)]
+
+    def trace_of(g, cfg, pose):
+        r = g.optimize(synth.to_xyzi(cfg["scan"]), pose)
+        tr = g.trace()
+        return (r.iters_run, r.converged, r.n_sel_last, np.array(r.pose, np.float32).view(np.uint32).tolist(),
+                [t.n_sel for t in tr], np.array([t.pose[:] for t in tr], np.float32).view(np.uint32).tolist())
+
+    monkeypatch.setenv("S2M_ABLATE", "3")
+    ref = []
+    for pose in poses:
+        g = s2m.MapOptimizationS2M(early_exit=0)
+        g.setInputCloud(synth.to_xyzi(small["map"]))
+        ref.append(trace_of(g, small, pose))
+        g.close()
+    monkeypatch.setenv("S2M_ABLATE", "0")
+    g = s2m.MapOptimizationS2M(early_exit=0)
+    for k, pose in enumerate(poses):
+        g.setInputCloud(synth.to_xyzi(tiny["map"]))                 # something else in between: stale rows everywhere
+        trace_of(g, tiny, tiny["pose_init"])
+        g.setInputCloud(synth.to_xyzi(small["map"]))
+        assert trace_of(g, small, pose) == ref[k], k
+    g.close()
