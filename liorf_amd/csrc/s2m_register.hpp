@@ -181,6 +181,8 @@ struct Fragile {
     int opos[5] = { 0, 0, 0, 0, 0 };
     int front[6] = { 0, 0, 0, 0, 0, 0 };
     v3f mm[6];
+    int alt[5] = { 0, 0, 0, 0, 0 };                       // the tuple the lane had before its present one, and that tuple's plane
+    v4f alt_plane = { NAN, 0.0f, 0.0f, 0.0f };            // (valid if state bit 4 is set)
 };
 
 template <bool HOOK>
@@ -1091,6 +1093,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
                     for (int j = 0; j < 5; j++) frag.opos[j] = G(cp->npos)[(size_t)j * nq + i];
 #pragma unroll
                     for (int j = 0; j < 6; j++) frag.front[j] = G(cp->nbr)[(size_t)j * nq + i];
+#pragma unroll
+                    for (int j = 0; j < 5; j++) frag.alt[j] = G(cp->npos_alt)[(size_t)j * nq + i];
+                    frag.alt_plane = G((const v4f*)cp->plane_alt)[i];
                 }
             };
             auto late = [&]() {
@@ -1174,9 +1179,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
                 }
                 quick = __ballot(need && !okl) == 0ull;
                 flip = flip && need && quick;
-                if (__ballot(flip)) {
-                    if (flip) {
-                        const int i = chunk.x + lane;
+                // A flip back to the tuple the lane had before (two nearly equidistant neighbours swapping places with every
+                // micro-step) finds that tuple's plane kept: the two are exchanged.  Anything else is fitted again (:1099-1122),
+                // and the tuple it replaces is kept with its plane.
+                bool back = flip && (frag.aux.y & 16) != 0;
+#pragma unroll
+                for (int k = 0; k < 5; k++) back = back && (int)key_lo(t.key[k]) == frag.alt[k];
+                v4f pl_new = frag.alt_plane;
+                if (__ballot(flip && !back)) {
+                    if (flip && !back) {
                         float qr[5][3], mx[5][3];
 #pragma unroll
                         for (int j = 0; j < 5; j++) {                                   // the five nearest, in order (:1099-1101)
@@ -1199,18 +1210,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
                             const float rr_ = pa * mx[j][0] + pb * mx[j][1] + pc * mx[j][2] + pd;
                             if ((double)fabsf(rr_) > cp->plane_tol) planeValid = false;
                         }
-                        const v4f pl = { planeValid ? pa : NAN, pb, pc, pd };
-                        G((v4f*)cp->plane_cache)[i] = pl;
-                        plane0 = pl;
-#pragma unroll
-                        for (int k = 0; k < 5; k++) G(cp->npos)[(size_t)k * nq + i] = (int)key_lo(t.key[k]);
-                        // the stored certificate spoke of the old order: none from now on (the reference position and the radii the
-                        // neighbourhood vouches for stay as they are)
-                        const v4f cnew = { cert.x, cert.y, cert.z, 0.0f };
-                        G((v4f*)cp->cert)[i] = cnew;
-                        const v4i anew = { frag.aux.x, (frag.aux.y & ~3) | (planeValid ? 1 : 2), frag.aux.z, frag.aux.w };
-                        G((v4i*)cp->aux)[i] = anew;
+                        pl_new = v4f{ planeValid ? pa : NAN, pb, pc, pd };
                     }
+                }
+                if (flip) {
+                    const int i = chunk.x + lane;
+                    G((v4f*)cp->plane_alt)[i] = plane0;                                 // what the lane had until now
+#pragma unroll
+                    for (int k = 0; k < 5; k++) G(cp->npos_alt)[(size_t)k * nq + i] = frag.opos[k];
+                    G((v4f*)cp->plane_cache)[i] = pl_new;
+#pragma unroll
+                    for (int k = 0; k < 5; k++) G(cp->npos)[(size_t)k * nq + i] = (int)key_lo(t.key[k]);
+                    plane0 = pl_new;
+                    // the stored certificate spoke of the old order: none from now on (the reference position and the radii the
+                    // neighbourhood vouches for stay as they are)
+                    const v4f cnew = { cert.x, cert.y, cert.z, 0.0f };
+                    G((v4f*)cp->cert)[i] = cnew;
+                    const v4i anew = { frag.aux.x, (frag.aux.y & ~3) | ((pl_new.x == pl_new.x) ? 1 : 2) | 16, frag.aux.z, frag.aux.w };
+                    G((v4i*)cp->aux)[i] = anew;
                 }
             }
             if (HOOK || __builtin_expect(__ballot(need) != 0ull && !quick, 0)) {     // (unlikely: the search is laid out away from the certified path)

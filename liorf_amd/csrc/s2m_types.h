@@ -61,9 +61,13 @@ struct DevCtx {
     float4*  cert;                // [n_q] {q_ref x,y,z: where the point stood when the tuple was established, slack: how far it may move}
     int4*    aux;                 // [n_q] {r_out (float bits): every map point outside the neighbourhood was at least this far from q_ref,
                                   //        state: bits 0-1 plane 0 none / 1 passed the inlier test / 2 failed it, bit 2 the tuple is complete,
-                                  //        bit 3 the neighbourhood is valid, number of neighbourhood members, spare}
+                                  //        bit 3 the neighbourhood is valid, bit 4 plane_alt / npos_alt are valid, number of neighbourhood members, spare}
     int32_t* nbr;                 // [kNbr][n_q] the neighbourhood: positions in map_sorted of EVERY map point within r_out of q_ref
     float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to the tuple; pa = NaN: this point contributes nothing
+    // the tuple (and its plane) a point had before its present one - state bit 4 says it is valid: two nearly equidistant
+    // neighbours swap places back and forth with the micro-steps of the converged loop, and the plane of either order is kept
+    float4*  plane_alt;           // [n_q]
+    int32_t* npos_alt;            // [5][n_q]
     int32_t n_q, n_m, nblocks;    // nblocks: workgroups of a k_register launch (<= kMaxBlocks; waves loop over the wave table)
     int32_t wpb;                  // waves per workgroup of k_register for this scan: kBlock / 64 or kBigWaves
     int32_t table_cap;            // capacity of wave_table in entries
