@@ -61,7 +61,7 @@ constexpr float kNbrReachCold = 0.10f; // ... and beyond the gate when it has no
 constexpr int   kWalkLanes = 64;       // a wave whose tile overflowed serves up to this many lanes one by one; beyond, every lane walks its own cells
 constexpr int   kNbr = kNbrCap;        // neighbourhood capacity (map positions per scan point)
 constexpr int   kLevels = 6;           // radii a search counts against at once
-constexpr float kFragileSlack = 1e-4f; // a certificate with less slack than this may well fail in the steady state of the loop: such a lane prefetches
+constexpr float kFragileSlack = 3e-5f; // a certificate with less slack than this may well fail in the steady state of the loop: such a lane prefetches
 constexpr int   kServeLanes = 4;       // up to this many searching lanes are served one by one instead of staging a tile
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));
