@@ -3,22 +3,30 @@
 
 A "step" is one scan2MapOptimization() of BASELINE configs[1]: a synthetic 120 000-point
 Velodyne-64 scan against a 200 000-point local surf map, 30 LM iterations (early exit
-disabled), inputs resident in HBM when the timed region starts.  With
-N GPUs every rank registers its own scan against a replicated map (weak scaling, no
-data-path collective) and the 8-float result records are all-gathered over RCCL per step.
+disabled), inputs resident in HBM when the timed region starts.  The
+steps cycle over 8 distinct seeded scans of the same map (synth.make_config(.., scan_index=k)),
+so K steps are not one problem K times.  With N GPUs every rank registers its own scans
+against a replicated map (weak scaling, no data-path collective) and the 8-float result
+records are all-gathered over RCCL per step.
 
   python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus N ...        (no WORLD_SIZE in the environment: starts the N ranks itself, as child processes,
+                                       before this process makes any GPU call, and relays rank 0's line)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `roofline` is the dominant kernel (k_register: kNN + plane +
-Jacobian + block reduction) priced against HBM; `cpu_baseline` is the CPU oracle (a port of
-the reference's OpenMP path; the reference itself cannot be built) timed on
-this box's host cores on a bounded sample of the same workload.
+Jacobian + block reduction) priced against HBM over the whole loop, `roofline_cold` the same for
+launch 0 of a scan alone (the pass that really searches every point: the kNN + plane pass of
+north_star); `cpu_baseline` is the CPU oracle (a port of the reference's OpenMP path; the
+reference itself cannot be built) timed on this box's host cores on a
+bounded sample of the same workload.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,27 +37,30 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12            # B/s, /opt/skills/guides/MI355X_MICROARCH.md (spec); 6.29e12 measured-achievable
 HBM_ACHIEVABLE = 6.29e12
+N_SCANS = 8                  # distinct seeded scans the timed steps cycle over
 
 
-def cpu_baseline(cfg, iters: int, threads: int, scans: int = 1):
+def cpu_baseline(cfg, iters: int, threads: int, scans: int = 1, early_exit: int = 0):
     """CPU oracle (kd-tree back-end, OpenMP over queries like reference :1078) on a bounded sample:
-    one warm-up registration, then `scans` registrations of `iters` LM iterations each (early exit off);
+    one warm-up registration, then `scans` registrations of up to `iters` LM iterations each (early exit as given);
     the rate is taken from the median registration."""
     from liorf_amd import synth
     from oracle import oracle as O
-    orc = O.Oracle(knn_backend=1, num_threads=threads, early_exit=0, max_iter=iters)
+    orc = O.Oracle(knn_backend=1, num_threads=threads, early_exit=early_exit, max_iter=iters)
     orc.set_map(synth.to_xyzi(cfg["map"]))
     orc.set_scan(synth.to_xyzi(cfg["scan"]))
     if scans > 1:
         orc.scan2MapOptimization(cfg["pose_init"])
-    times = []
+    times, iters_run = [], iters
     for _ in range(scans):
         t0 = time.perf_counter()
-        orc.scan2MapOptimization(cfg["pose_init"])
+        r = orc.scan2MapOptimization(cfg["pose_init"])
         times.append(time.perf_counter() - t0)
+        iters_run = r.iters_run
     dt = float(np.median(times))
     tm = orc.timing()
-    return dict(iters_per_s=iters / dt, seconds=float(np.sum(times)), tree_build_s=tm.tree_build, knn_plane_s=tm.knn_plane,
+    return dict(iters_per_s=iters_run / dt, seconds=float(np.sum(times)), ms_per_scan=1e3 * dt, iters_run=iters_run,
+                tree_build_s=tm.tree_build, knn_plane_s=tm.knn_plane,
                 compaction_s=tm.compaction, jacobian_solve_s=tm.jacobian_solve)
 
 
@@ -63,7 +74,7 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -72,8 +83,51 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--cpu-scans", type=int, default=10)
-    ap.add_argument("--batch", action="store_true", help="also time 2 and 4 scans in flight against one map (s2m_optimize_batch)")
-    args = ap.parse_args()
+    ap.add_argument("--batch", action="store_true", help="also time 2, 4 and 8 scans in flight against one map (s2m_optimize_batch)")
+    ap.add_argument("--print-launch", action="store_true", help="print the command that would start the ranks and exit (no GPU call)")
+    return ap.parse_args(argv)
+
+
+def rank_launch_command(n_gpus: int, argv: list[str], port: int | None = None) -> list[str]:
+    """The command that runs this benchmark as `n_gpus` ranks of one node, one process per GPU (RCCL rendezvous on 127.0.0.1)."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def start_ranks_if_asked(args, argv) -> None:
+    """`--gpus N` with N > 1 and no WORLD_SIZE: this process has made no GPU call yet (importing torch and counting devices make
+    none on this image), so it may start the N ranks as fresh child processes; it relays their output and exit code.  A rank
+    count that disagrees with --gpus is refused: silently running one rank and printing n_gpus: 1 was round 2's bug."""
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is not None:
+        if int(world_env) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: start exactly --gpus ranks "
+                             f"(python bench.py --gpus N starts them itself when WORLD_SIZE is not set)")
+        return
+    if args.gpus <= 1 and not args.print_launch:
+        return
+    cmd = rank_launch_command(args.gpus, [a for a in argv if a != "--print-launch"])
+    if args.print_launch:
+        print(" ".join(cmd))
+        raise SystemExit(0)
+    import torch
+    have = torch.cuda.device_count()                      # (no HIP initialisation: counting devices is not a GPU call here)
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {have} visible: refusing to run fewer ranks than asked for")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env)                   # children write to our stdout / stderr: rank 0's JSON line passes through
+    raise SystemExit(proc.returncode)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    start_ranks_if_asked(args, argv)
 
     import torch
     import torch.distributed as dist
@@ -82,6 +136,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the registration path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -89,13 +144,15 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
-    # ---- workload: same map on every rank, one scan per rank (BASELINE configs[3]) ----------
-    cfg = synth.make_config(args.workload, scan_index=rank)
+    # ---- workload: same map on every rank, every rank its own N_SCANS seeded scans (BASELINE configs[3]) ----------
+    cfgs = [synth.make_config(args.workload, scan_index=(rank * N_SCANS + k) % 64) for k in range(N_SCANS)]
+    cfg = cfgs[0]
     n_q, n_m = cfg["scan"].shape[0], cfg["map"].shape[0]
     eng = s2m.MapOptimizationS2M(device_id=local_rank, early_exit=0)
-    # inputs resident in HBM before the timed region: raw PointXYZI records of map and scan
+    # inputs resident in HBM before the timed region: raw PointXYZI records of map and scans
     d_map = torch.from_numpy(synth.to_xyzi(cfg["map"])).to(dev)
-    d_scan = torch.from_numpy(synth.to_xyzi(cfg["scan"])).to(dev)
+    d_scans = [torch.from_numpy(synth.to_xyzi(c["scan"])).to(dev) for c in cfgs]
+    d_scan = d_scans[0]
     torch.cuda.synchronize()
     for _ in range(2):          # second call = steady state (buffers already sized)
         eng.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
@@ -103,18 +160,20 @@ def main():
         tm = eng.timing()
     max_iter = eng.params.max_iter
 
-
     gatherer = batch.RecordGatherer(world, device=dev) if world > 1 else None
+    counter = [0]
 
     def step():
         # one scan2MapOptimization(): scan ordering/SoA prep + 30 x {k_register, k_finalize}; the map
         # index (the reference's kd-tree build, once per scan) is timed separately, see map_index_build_ms
-        eng.setScanDevice(d_scan.data_ptr(), n_q, 32)
-        eng.launch(cfg["pose_init"])
+        k = counter[0] % N_SCANS
+        counter[0] += 1
+        eng.setScanDevice(d_scans[k].data_ptr(), n_q, 32)
+        eng.launch(cfgs[k]["pose_init"])
         r = eng.collect()
         if world > 1:      # RCCL all-gather of {pose[6], iters, n_sel} over xGMI: every rank gets all poses
             gatherer.gather(batch.pack_record(r.pose, r.iters_run, r.n_sel_last)[None, :])
-        return r
+        return r, k
 
     def fence():
         if world > 1:
@@ -122,11 +181,11 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        r = step()
+        r, k_last = step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        r = step()
+        r, k_last = step()
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -141,24 +200,30 @@ def main():
         fence()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            r = step()
+            r, k_last = step()
         fence()
         windows.append(1e3 * (time.perf_counter() - t1) / args.steps)
+    device_ms = eng.timing()["optimize_ms"]
 
-    # ---- dominant kernel, timed live with HIP events on the library's stream ------------------
+    # ---- dominant kernel, timed live with HIP events on the library's stream (scan 0) ---------
+    eng.setScanDevice(d_scan.data_ptr(), n_q, 32)
     per_iter_ms = eng.time_iterations(cfg["pose_init"], reps=10)       # 10 loops x 30 launches, event pair per launch (diagnostic)
     # the figure the roofline uses: 10 whole loops, HIP events around launch 0, launch 1, the back-to-back run 2..28, launch 29 - an
     # event pair around every launch (above) breaks up the back-to-back dispatch and adds ~4 us to each
     kernel_ms = eng.time_loop_launches(cfg["pose_init"], reps=10) * 1e-3
     b_alg = 12.0 * (n_q + n_m)                             # SoA fp32 xyz read once
     achieved = b_alg / (kernel_ms * 1e-3)
+    # launch 0 of a scan on its own: every point searches from scratch (no certificate, no prior) - the kNN + plane pass
+    cold_ms = float(per_iter_ms[0])
+    achieved_cold = b_alg / (cold_ms * 1e-3)
     # HBM-side bytes per launch from the committed PMC passes of this workload (profiles/): FETCH_SIZE is doubled (the gfx950
     # correction for 16-B-per-lane reads, MI355X_MICROARCH.md), WRITE_SIZE as is.  The counters need rocprofv3 and cannot be
     # taken inside this run; they are reported only if they were taken on the kernel sources that are running (the file is
     # stamped with a hash of liorf_amd/csrc), otherwise traffic is null and traffic_stale says why.
     traffic = traffic_raw = None
     traffic_stale = None
-    pmc_file = os.path.join(ROOT, "profiles", f"r02_k_register_pmc_{args.workload}.json")
+    pmc_name = f"r03_k_register_pmc_{args.workload}.json"
+    pmc_file = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
         if pmc.get("kernel_source_sha") == s2m.kernel_source_sha():
@@ -168,32 +233,57 @@ def main():
             traffic_stale = False
         else:
             traffic_stale = True
-    device_ms = eng.timing()["optimize_ms"]
+    # per-launch-index durations of the same command under rocprofv3 --kernel-trace (tools/launch_index_stats.py), if they
+    # were taken on these kernel sources: the figure to trust for a single launch (no event packets around it)
+    cold_rocprof_us = None
+    lis_file = os.path.join(ROOT, "profiles", f"r03_launch_index_stats_{args.workload}.json")
+    if os.path.exists(lis_file):
+        lis = json.load(open(lis_file))
+        if lis.get("kernel_source_sha") == s2m.kernel_source_sha():
+            cold_rocprof_us = lis["us_by_launch_index"][0]
 
     # ---- what the reference actually does: break when LMOptimization() returns true (:1313) -----------------------
     early = {}
     if world == 1:
         e2 = s2m.MapOptimizationS2M(device_id=local_rank, early_exit=1)
         e2.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
-        ts = []
-        for k in range(13):
+        ts, its = [], []
+        for j in range(3 + 2 * N_SCANS):
+            k = j % N_SCANS
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            e2.setScanDevice(d_scan.data_ptr(), n_q, 32)
-            e2.launch(cfg["pose_init"])
+            e2.setScanDevice(d_scans[k].data_ptr(), n_q, 32)
+            e2.launch(cfgs[k]["pose_init"])
             r2 = e2.collect()
             ts.append(time.perf_counter() - t1)
-        early = {"ms_per_scan_early_exit": round(1e3 * float(np.median(ts[3:])), 4), "iters_run_early_exit": r2.iters_run,
+            its.append(r2.iters_run)
+        ts, its = ts[3:], its[3:]
+        early = {"ms_per_scan_early_exit": round(1e3 * float(np.median(ts)), 4),
+                 "iters_run_early_exit": round(float(np.mean(its)), 2),
+                 "lm_iterations_per_s_early_exit": round(float(np.sum(its)) / float(np.sum(ts)), 1),
+                 "scans_per_s_early_exit": round(len(ts) / float(np.sum(ts)), 1),
                  "device_ms_early_exit": round(e2.timing()["optimize_ms"], 4)}
+        # the same per scan as INTEGRATION.md section 2's minimal binding does it: s2m_set_map + s2m_optimize on HOST records
+        # (pageable memory as a ROS node holds it): map upload + index build + scan upload + ordering + loop, every scan
+        h_map = synth.to_xyzi(cfg["map"])
+        h_scans = [synth.to_xyzi(c["scan"]) for c in cfgs]
+        th = []
+        for j in range(2 + N_SCANS):
+            k = j % N_SCANS
+            t1 = time.perf_counter()
+            e2.setInputCloud(h_map)
+            e2.optimize(h_scans[k], cfgs[k]["pose_init"])
+            th.append(time.perf_counter() - t1)
+        early["ms_per_scan_host_buffers_early_exit"] = round(1e3 * float(np.median(th[2:])), 4)
         # ---- several scans against the same map in one graph (BASELINE config 4 on one GPU) ---------------------------
         batch_out = []
         if args.batch:
-            d_more = [d_scan] + [torch.from_numpy(synth.to_xyzi(synth.make_config(args.workload, scan_index=k)["scan"])).to(dev) for k in range(1, 4)]
-            p_more = np.stack([cfg["pose_init"]] + [synth.make_config(args.workload, scan_index=k)["pose_init"] for k in range(1, 4)]).astype(np.float32)
-            for B in (2, 4):
+            p_more = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
+            eng.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
+            for B in (2, 4, 8):
                 def bstep():
                     for b in range(B):
-                        eng.batchSetScan(b, device_ptr=(d_more[b].data_ptr(), int(d_more[b].shape[0]), 32))
+                        eng.batchSetScan(b, device_ptr=(d_scans[b].data_ptr(), int(d_scans[b].shape[0]), 32))
                     eng.batchLaunch(p_more[:B])
                     return eng.batchCollect()
                 for _ in range(2):
@@ -224,30 +314,42 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"{args.workload}: {n_q}-pt scan vs {n_m}-pt local surf map, {max_iter} LM iterations per "
-                        f"scan (early exit off), one scan per GPU, map replicated",
-            "n_q": n_q, "n_m": n_m, "lm_iters_per_step": max_iter,
+                        f"scan (early exit off), one scan per GPU at a time, {N_SCANS} distinct seeded scans in rotation, map replicated",
+            "n_q": n_q, "n_m": n_m, "lm_iters_per_step": max_iter, "distinct_scans": N_SCANS,
             "parallelism": f"scan-per-gpu x{world}" + (" + RCCL all_gather of 8-float records" if world > 1 else ""),
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_register",
             "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw, "traffic_stale": traffic_stale,
-            "traffic_source": f"profiles/r02_k_register_pmc_{args.workload}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+            "traffic_source": f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                               "stamped with the hash of the kernel sources it was taken on)",
             "algorithmic_bytes_per_launch": b_alg, "kernel_us": round(kernel_ms * 1e3, 3),
             "kernel_us_event_pair_per_launch": round(float(per_iter_ms.mean()) * 1e3, 3),
             "frac_of_measured_achievable": round(achieved / HBM_ACHIEVABLE, 5),
         },
+        # launch 0 of a scan: the pass that searches every point (what reference :1085-1122 does in every iteration)
+        "roofline_cold": {
+            "bound": "hbm", "kernel": "k_register, launch 0 of a scan (no certificate, no prior: every point searches)",
+            "achieved": round(achieved_cold / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(achieved_cold / HBM_PEAK, 5), "algorithmic_bytes_per_launch": b_alg,
+            "kernel_us": round(cold_ms * 1e3, 2), "kernel_us_source": "HIP event pair around launch 0, mean of 10 loops (live)",
+            "kernel_us_rocprof": cold_rocprof_us,
+            "kernel_us_rocprof_source": f"profiles/r03_launch_index_stats_{args.workload}.json (rocprofv3 --kernel-trace of this "
+                                        "command, dispatches numbered inside their loop; null unless taken on the running sources)",
+        },
         "ms_per_step_windows": {"min": round(min(windows), 4), "median": round(float(np.median(windows)), 4), "max": round(max(windows), 4), "n": len(windows)},
         "kernel_us_by_iteration": [round(float(v) * 1e3, 1) for v in per_iter_ms],
         "kernel_us_steady_back_to_back": round(eng.time_steady(cfg["pose_init"], 200, True), 2),
         **early,
-        "knn_mpts_per_s": round(n_q / (kernel_ms * 1e-3) / 1e6, 1),
+        # kNN rate = the pass that searches: launch 0 (round 2 divided by the loop mean, most of whose launches search nothing)
+        "knn_mpts_per_s": round(n_q / (cold_ms * 1e-3) / 1e6, 1),
+        "points_per_s_loop_mean": round(n_q / (kernel_ms * 1e-3), 1),
         "device_ms_per_step": round(device_ms, 4),
         "map_index_build_ms": round(tm["set_map_ms"], 4),
         "scan_prep_ms": round(tm["set_scan_ms"], 4),
-        "last_result": {"iters_run": r.iters_run, "converged": r.converged, "n_sel": r.n_sel_last,
-                        "pose_err_m": float(np.abs(np.array(r.pose)[3:] - cfg["pose_gt"][3:]).max())},
+        "last_result": {"iters_run": r.iters_run, "converged": r.converged, "n_sel": r.n_sel_last, "scan_index": k_last,
+                        "pose_err_m": float(np.abs(np.array(r.pose)[3:] - cfgs[k_last]["pose_gt"][3:]).max())},
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -257,17 +359,24 @@ def main():
         ncpu = max(1, min(len(os.sched_getaffinity(0)), 16))
         b4 = cpu_baseline(cfg, args.cpu_iters, 4, args.cpu_scans)     # ~4 s wall, ~15 s of core time
         ball = cpu_baseline(cfg, args.cpu_iters, ncpu, 1)
+        b4e = cpu_baseline(cfg, args.cpu_iters, 4, 3, early_exit=1)   # the reference's loop semantics (:1313), per scan
         out["cpu_baseline"] = {
             "value": round(b4["iters_per_s"], 3), "unit": "LM iterations/s", "cores": 4, "kind": "port",
             "host": {"cpu_model": cpu_model(), "nproc": ncpu_all, "threads_granted": ncpu},
-            "sample": f"{args.cpu_scans} registrations x {args.cpu_iters} LM iterations of the same {n_q}x{n_m} workload, oracle "
+            "sample": f"{args.cpu_scans} registrations x {args.cpu_iters} LM iterations of the same {n_q}x{n_m} workload (scan 0), oracle "
                       f"kd-tree back-end, OpenMP 4 threads (reference numberOfCores, config/kitti.yaml:63), "
                       f"median registration after one warm-up, {b4['seconds']:.1f} s wall in total; kd-tree build excluded; "
                       f"stage_seconds are those of the last registration",
             "stage_seconds": {k: round(v, 4) for k, v in b4.items() if k.endswith("_s")},
             "all_cores": {"value": round(ball["iters_per_s"], 3), "cores": ncpu},
+            "early_exit": {"ms_per_scan": round(b4e["ms_per_scan"], 3), "iters_run": b4e["iters_run"], "cores": 4,
+                           "sample": "3 registrations of scan 0 with the reference's break (:1313), median, kd-tree build excluded"},
         }
+        # like for like: fixed 30 iterations against fixed 30 (the CPU searches in all of them, the GPU proves most of them
+        # unchanged), and one scan with the reference's break against one scan with the reference's break
         out["speedup_vs_cpu_4t"] = round(value / b4["iters_per_s"], 1)
+        if early:
+            out["speedup_vs_cpu_4t_per_scan_early_exit"] = round(b4e["ms_per_scan"] / early["ms_per_scan_early_exit"], 1)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -186,10 +186,34 @@ int check_records(s2m_context* h, const void* pts, size_t n, size_t stride)
     return S2M_OK;
 }
 
+int set_map_build(s2m_context* h, const void* pts, size_t n, size_t stride, bool on_device);
+
+// The index is rebuilt in place: once the rebuild has started the old index is gone, so a failure on the way leaves the handle
+// with NO map (n_m = 0, the reference's "no key poses yet" state, :1297), a new map epoch (batch slots drop what they adopted)
+// and no certificates - never the old point count over half-rewritten buffers.
 int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool on_device)
 {
     int rc = check_records(h, pts, n, stride);
     if (rc) return rc;
+    rc = set_map_build(h, pts, n, stride, on_device);
+    if (rc != S2M_OK && n > 0) {
+        const std::string why = h->err;
+        h->map_epoch++;
+        h->n_m = 0; h->hctx.n_m = 0; h->ctx_dirty = true;
+        if (h->have_scan && h->n_q > 0 && h->cert.p) {
+            (void)hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream);
+            (void)hipMemsetAsync(h->aux.p, 0, sizeof(int4) * h->n_q, h->stream);
+        }
+        (void)upload_ctx(h);
+        (void)hipStreamSynchronize(h->stream);
+        h->err = why;
+    }
+    return rc;
+}
+
+int set_map_build(s2m_context* h, const void* pts, size_t n, size_t stride, bool on_device)
+{
+    int rc;
     S2M_HIP(h, hipSetDevice(h->device));
     S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
     if (n == 0) { h->map_epoch++; h->n_m = 0; h->hctx.n_m = 0; h->ctx_dirty = true; h->t_set_map_ms = 0; return upload_ctx(h); }
@@ -250,7 +274,7 @@ int set_map_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool 
         S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int4) * h->n_q, h->stream));
     }
     h->map_epoch++;
-    h->n_m = n;                                       // committed only now: a failure above leaves the old index in place
+    h->n_m = n;                                       // committed only now; a failure above leaves no map at all (set_map_impl)
     h->hctx.n_m = (int32_t)n;
     h->hctx.g = g;
     h->hctx.map_sorted = h->map_sorted.as<float4>();
@@ -758,6 +782,8 @@ int s2m_set_params(s2m_handle h, const s2m_params* p)
         S2M_HIP(h, hipStreamSynchronize(h->stream));
         for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
         h->graphs.clear();
+        for (auto& kv : h->batch_graphs) (void)hipGraphExecDestroy(kv.second);     // (every branch of a batch graph is such a loop)
+        h->batch_graphs.clear();
     }
     h->prm = *p;
     params_to_ctx(h, h->prm);                           // uploaded by the next call that launches anything
@@ -861,6 +887,16 @@ int s2m_optimize(s2m_handle h, const void* scan, size_t n, size_t stride_bytes, 
 // ---- a batch of scans against one resident map -------------------------------------------------------
 namespace {
 
+// field by field (the struct has padding): everything a slot has to take over from its parent
+bool same_params_but_stream(const s2m_params& a, const s2m_params& b)
+{
+    return a.struct_size == b.struct_size && a.device_id == b.device_id && a.k_neighbors == b.k_neighbors && a.gate_sq == b.gate_sq &&
+           a.plane_tol == b.plane_tol && a.weight_scale == b.weight_scale && a.weight_min == b.weight_min && a.min_corr == b.min_corr &&
+           a.min_feats == b.min_feats && a.max_iter == b.max_iter && a.eig_thresh == b.eig_thresh && a.conv_deg == b.conv_deg &&
+           a.conv_cm == b.conv_cm && a.z_tol == b.z_tol && a.rot_tol == b.rot_tol && a.imu_type == b.imu_type &&
+           a.imu_rpy_weight == b.imu_rpy_weight && a.early_exit == b.early_exit;
+}
+
 // child b borrows the parent's map index (no copy) and its per-scan certificates are void when the index changed
 int adopt_map(s2m_context* h, s2m_context* k)
 {
@@ -956,12 +992,10 @@ int s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses)
     for (int b = 0; b < n_scans; b++) {
         s2m_context* k = h->kids[(size_t)b];
         if (!k->have_scan) return fail(h, S2M_ERR_NO_SCAN, "s2m_batch_set_scan has not been called for every slot");
-        if (k->prm.early_exit != h->prm.early_exit || k->prm.max_iter != h->prm.max_iter || memcmp(&k->prm.gate_sq, &h->prm.gate_sq, sizeof(double)) != 0) {
-            s2m_params p = h->prm;                         // parameters changed on the parent since the slot was made
+        if (!same_params_but_stream(k->prm, h->prm)) {     // any parameter changed on the parent since the slot was made
+            s2m_params p = h->prm;
             p.stream = k->prm.stream;
             if ((rc = s2m_set_params(k, &p))) return fail(h, rc, k->err.c_str());
-        } else {
-            k->prm.z_tol = h->prm.z_tol; k->prm.rot_tol = h->prm.rot_tol; k->prm.imu_type = h->prm.imu_type; k->prm.imu_rpy_weight = h->prm.imu_rpy_weight;
         }
         if ((rc = adopt_map(h, k))) return fail(h, rc, k->err.c_str());
         memcpy(k->pending_pose_in, poses + 6 * (size_t)b, 24);

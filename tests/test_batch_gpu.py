@@ -75,6 +75,33 @@ def test_batch_follows_map_and_parameter_changes(cfg_tiny, cfg_small):
     gpu.close()
 
 
+def test_batch_follows_every_parameter_of_the_parent(cfg_small):
+    """Round-2 advisor finding: a max_iter change on the parent left the batch graph with the old number of launches, and
+    plane_tol / weight_* / min_corr / eig_thresh / conv_* never reached the slots.  Change them between two batches on one
+    handle: every slot must give, bit for bit, what a fresh handle created with those parameters gives."""
+    m, s = synth.to_xyzi(cfg_small["map"]), synth.to_xyzi(cfg_small["scan"])
+    p = np.stack([cfg_small["pose_init"], cfg_small["pose_init"] + np.float32(0.004)]).astype(np.float32)
+    gpu = s2m.MapOptimizationS2M(early_exit=0)
+    gpu.setInputCloud(m)
+    gpu.optimizeBatch([s, s], p)                                   # slots and the 30-launch batch graph exist now
+    steps = [dict(max_iter=12), dict(plane_tol=0.05, weight_scale=0.7, weight_min=0.3), dict(max_iter=30, conv_deg=0.5, conv_cm=0.5, early_exit=1),
+             dict(min_corr=100000), dict(min_corr=50, eig_thresh=1e9)]
+    have = dict(early_exit=0)
+    for kw in steps:
+        have.update(kw)
+        gpu.setParams(**kw)
+        out, res = gpu.optimizeBatch([s, s], p)
+        for b in range(2):
+            want = _solo(m, s, p[b], **have)
+            assert (res[b].iters_run, res[b].converged, res[b].is_degenerate, res[b].n_sel_last, res[b].skipped) == want[1], (kw, b)
+            assert np.array_equal(out[b].view(np.uint32), want[0].view(np.uint32)), (kw, b)
+            tr = np.array([t.pose[:] for t in gpu.batchTrace(b)], np.float32)
+            assert tr.shape == want[3].shape and np.array_equal(tr.view(np.uint32), want[3].view(np.uint32)), (kw, b)
+        if "max_iter" in kw and kw["max_iter"] == 12:
+            assert res[0].iters_run == 12
+    gpu.close()
+
+
 def test_batch_of_eight_kitti64_scans(cfg_kitti64):
     """BASELINE config 4's batch (8 scans from 8 seeded poses along a path, one map) on one GPU."""
     m = synth.to_xyzi(cfg_kitti64["map"])

@@ -66,8 +66,10 @@ def _loop(cfg, ablate, monkeypatch, early_exit):
     return out
 
 
-@pytest.mark.parametrize("name", ["small", "kitti64"])
+@pytest.mark.parametrize("name", ["small", "kitti64", "ouster128", "dense1m"])
 def test_loop_with_and_without_certificates_is_bitwise_the_same(name, monkeypatch):
+    """At ouster128 / dense1m this runs the 16-wave workgroups, waves with several wave-table entries and their certificate
+    pre-check - paths the oracle comparison at those sizes sees only through its 1e-4 tolerance."""
     cfg = synth.make_config(name)
     for early_exit in (0, 1):
         ref = _loop(cfg, "3", monkeypatch, early_exit)            # every launch searches every point
@@ -159,13 +161,14 @@ def test_loop_in_two_ranges_equals_the_loop_in_one_piece(monkeypatch):
         assert (one[0] > 8) == past_first, one[0]          # (the tight thresholds take the loop past both first ranges)
 
 
-def test_reused_handle_gives_bitwise_the_loop_of_a_fresh_one_that_searches_everything(monkeypatch):
+@pytest.mark.parametrize("size", ["small", "ouster128"])
+def test_reused_handle_gives_bitwise_the_loop_of_a_fresh_one_that_searches_everything(monkeypatch, size):
     """Per-point state of earlier scans (tuples, neighbourhoods, planes) stays in the handle's buffers; only the state
     words are reset by s2m_set_scan.  Rows of a neighbourhood beyond its member count hold stale map positions - a
     path that matched against them (the in-line re-measurement did, once) gives results that depend on what ran before.
     A handle that has registered other scans against other maps must produce, bit for bit, the trace of a fresh
     handle with certificates and re-measuring switched off."""
-    small, tiny = synth.make_config("small"), synth.make_config("tiny")
+    small, tiny = synth.make_config(size), synth.make_config("tiny")
     poses = [small["pose_init"], (small["pose_init"] + np.float32(0.01)).astype(np.float32),
              (small["pose_init"] + np.array([0.002, -0.001, 0.004, 0.05, -0.03, 0.02], np.float32)).astype(np.float32)]
 
