@@ -98,6 +98,9 @@ struct s2m_context {
     int  seg_iters = 8;                // with early exit on, the loop is issued as launches 0..seg-1 and, only if those did not converge, the rest (env S2M_SEGMENT, 0 = one piece)
     bool seg_pending = false;          // the launch in flight was the first range only
     hipEvent_t ev_a2 = nullptr, ev_b2 = nullptr;
+    int  split_mode = -1;              // env S2M_SPLIT: 1 = every loop runs certify + search kernels, 0 = every loop the fused kernel, default: split for the
+                                       // scan slots of a batch and for 16-wave workgroups (large scans), fused for a single small scan
+    bool lockstep = true;              // env S2M_LOCKSTEP=0: the scans of a batch as parallel branches of the graph instead of one grid row each (A/B measurements)
     bool big_blocks = true;            // env S2M_BIG_BLOCKS=0: 8-wave workgroups whatever the scan size (A/B measurements)
     int density_raw = 320;             // box points above which a wave asks for a finer cut (env S2M_DENSITY_RAW, 0 = off)
     bool opt_pending = false;
@@ -132,6 +135,19 @@ int ensure(s2m_context* h, DevBuf& b, size_t bytes)
     if (b.p) { S2M_HIP(h, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
     S2M_HIP(h, hipMalloc(&b.p, want));
     b.cap = want;
+    h->ctx_dirty = true;
+    return S2M_OK;
+}
+
+// the partial rows of a launch (two slots, by launch parity) and, behind them, the search kernel's worklist
+int ensure_rows(s2m_context* h, int nblocks)
+{
+    const size_t rows = sizeof(double) * 2 * kAcc * (size_t)nblocks;
+    int rc = ensure(h, h->partials, rows + 64 + sizeof(int32_t) * 2 * (size_t)nblocks);
+    if (rc) return rc;
+    h->hctx.partials = h->partials.as<double>();
+    h->hctx.wl_count = reinterpret_cast<int32_t*>(h->partials.as<unsigned char>() + rows);
+    h->hctx.wl_items = h->hctx.wl_count + 16;
     h->ctx_dirty = true;
     return S2M_OK;
 }
@@ -316,8 +332,7 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     h->hctx.nblocks = nblocks;
     h->hctx.table_cap = table_cap;
     h->ctx_dirty = true;
-    if ((rc = ensure(h, h->partials, sizeof(double) * 2 * kAcc * (size_t)nblocks))) return rc;   // two slots, by launch parity
-    h->hctx.partials = h->partials.as<double>();
+    if ((rc = ensure_rows(h, nblocks))) return rc;
     if (n == 0) { h->t_set_scan_ms = 0; h->scan_timing_pending = false; return upload_ctx(h); }
 
     const unsigned char* d_pts;
@@ -429,60 +444,118 @@ int push_state(s2m_context* h, const float pose[6])
     return S2M_OK;
 }
 
-// The LM loop (:1304-1315) as a launch sequence.  k_register(L) does the per-point work of iteration L.
-// When the whole grid is co-resident (<= 2 workgroups on each of the 256 CUs) iterations 1..n-2 are closed
-// inside the prologue of the following k_register (solve_prev): every workgroup repeats the small solve, and
+// The LM loop (:1304-1315) as a launch sequence.  One iteration L is either one launch of the fused kernel R(L), or -
+// split - the certify kernel C(L) followed by the search kernel S(L) for the workgroups C put on its worklist (launch 0 of a
+// scan, where nothing is certified yet: S alone, over every workgroup).  When the whole grid is co-resident iterations
+// 1..n-2 are closed inside the prologue of the following R / C (solve_prev): every workgroup repeats the small solve, and
 // a kernel boundary plus a one-workgroup kernel disappear from every iteration:
 //   R0 F0 R1 R2' R3' ... R(n-1)' F(n-1)        (' = closes the iteration before it)
-// Larger grids run in several rounds per CU, each round would pay the prologue again, and the plain
-//   R0 F0 R1 F1 ... R(n-1) F(n-1)
-// is faster (ouster128: 15.3k vs 14.2k LM iterations/s).
-// `events`, if given, holds 2*n events recorded around every k_register launch.
+//   S0 F0 C1 S1 C2' S2 ... C(n-1)' S(n-1) F(n-1)
+// The plain form  R0 F0 R1 F1 ...  remains for A/B measurements (S2M_NO_FUSE=1).
+// Several scan slots (a batch) advance in lockstep: every launch has one grid row per slot.
 constexpr int kFuseMaxBlocks = 512;
 
-// `events`, if given, holds 2*n events recorded around every k_register launch; with `coarse` only four pairs are recorded - around
-// launch 0, launch 1, the run of back-to-back launches 2 .. n-2 (slots 4, 5) and launch n-1 (slots 6, 7) - so that the event
-// packets do not break up the loop's back-to-back dispatch.
-// one k_register launch in the workgroup shape of the resident scan (DevCtx::wpb)
-inline void launch_register(s2m_context* h, bool hook, int nblocks, const DevCtx* dc, DevState* st, int L, int solve_prev)
+// what one loop launches over: the scan slots (one for a single scan), the widest grid among them, their common workgroup shape
+struct LoopShape {
+    SlotTable tbl;
+    int nslots = 1;
+    int nblocks = 0;        // grid.x of the registration kernels: the largest DevCtx::nblocks among the slots
+    int table_cap = 0;      // the largest wave-table capacity among the slots (grid of k_wave_density)
+    int wpb = kBlock / 64;  // waves per workgroup (DevCtx::wpb, the same for every slot)
+    bool batch = false;     // scan slots of a batch
+    bool split = false;     // C + S per iteration instead of R
+};
+
+LoopShape shape_of(s2m_context* h)
+{
+    LoopShape sh;
+    memset(&sh.tbl, 0, sizeof(sh.tbl));
+    sh.tbl.ctx[0] = h->dctx.as<DevCtx>();
+    sh.tbl.st[0] = h->state.as<DevState>();
+    sh.nslots = 1; sh.nblocks = h->hctx.nblocks; sh.table_cap = h->hctx.table_cap; sh.wpb = h->hctx.wpb;
+    sh.batch = h->parent != nullptr;
+    sh.split = h->split_mode == 1 || (h->split_mode < 0 && (sh.batch || sh.wpb == kBigWaves));
+    return sh;
+}
+
+template <bool HOOK, int NW, int MINW, int MODE, int CNW>
+inline void launch_k(hipStream_t s, const LoopShape& sh, int L, int flags)
+{
+    hipLaunchKernelGGL((k_register<HOOK, NW, MINW, MODE, CNW>), dim3(sh.nblocks, sh.nslots), dim3(NW * 64), 0, s, sh.tbl, L, flags);
+}
+
+// one fused launch R(L) in the workgroup shape of the scan (DevCtx::wpb); `hook`: the observation variant
+inline void launch_fused(s2m_context* h, const LoopShape& sh, bool hook, int L, int solve_prev)
 {
     constexpr int NW = kBlock / 64;
-    if (h->hctx.wpb == kBigWaves) {
-        if (hook) hipLaunchKernelGGL((k_register<true, kBigWaves, 4>), dim3(nblocks), dim3(kBigWaves * 64), 0, h->stream, dc, st, L, solve_prev);
-        else      hipLaunchKernelGGL((k_register<false, kBigWaves, 4>), dim3(nblocks), dim3(kBigWaves * 64), 0, h->stream, dc, st, L, solve_prev);
-    } else if (h->parent) {
-        // a scan slot of a batch: the 128-register build, so that two scans' workgroups share a CU
-        if (hook) hipLaunchKernelGGL((k_register<true, NW, 4>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
-        else      hipLaunchKernelGGL((k_register<false, NW, 4>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
+    const int fl = solve_prev ? kFlagSolvePrev : 0;
+    if (sh.wpb == kBigWaves) {
+        if (hook) launch_k<true, kBigWaves, 4, kFused, kBigWaves>(h->stream, sh, L, fl);
+        else      launch_k<false, kBigWaves, 4, kFused, kBigWaves>(h->stream, sh, L, fl);
     } else {
-        if (hook) hipLaunchKernelGGL((k_register<true, NW, 2>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
-        else      hipLaunchKernelGGL((k_register<false, NW, 2>), dim3(nblocks), dim3(kBlock), 0, h->stream, dc, st, L, solve_prev);
+        if (hook) launch_k<true, NW, 2, kFused, NW>(h->stream, sh, L, fl);
+        else      launch_k<false, NW, 2, kFused, NW>(h->stream, sh, L, fl);
     }
+}
+
+// the search kernel S(L): over the worklist C(L) left, or (all) over every workgroup
+inline void launch_search(s2m_context* h, const LoopShape& sh, int L, bool all)
+{
+    constexpr int NW = kBlock / 64;
+    const int fl = all ? kFlagAll : 0;
+    if (sh.wpb == kBigWaves) launch_k<false, NW, 2, kSearch, kBigWaves>(h->stream, sh, L, fl);
+    else                     launch_k<false, NW, 2, kSearch, NW>(h->stream, sh, L, fl);
+}
+
+inline void launch_certify(s2m_context* h, const LoopShape& sh, int L, int solve_prev)
+{
+    constexpr int NW = kBlock / 64;
+    const int fl = solve_prev ? kFlagSolvePrev : 0;
+    if (sh.wpb == kBigWaves) launch_k<false, kBigWaves, kCertifyWavesBig, kCertify, kBigWaves>(h->stream, sh, L, fl);
+    else                     launch_k<false, NW, kCertifyWaves, kCertify, NW>(h->stream, sh, L, fl);
+}
+
+// iteration L of the loop: R(L), or C(L) S(L)
+inline void launch_iteration(s2m_context* h, const LoopShape& sh, int L, int solve_prev)
+{
+    if (!sh.split) { launch_fused(h, sh, false, L, solve_prev); return; }
+    if (L == 0) { launch_search(h, sh, 0, true); return; }
+    launch_certify(h, sh, L, solve_prev);
+    launch_search(h, sh, L, false);
+}
+
+inline void launch_finalize(s2m_context* h, const LoopShape& sh, int L, int mode)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1, sh.nslots), dim3(kFinThreads), 0, h->stream, sh.tbl, L, mode);
+}
+
+inline void launch_density(s2m_context* h, const LoopShape& sh)
+{
+    // re-split the wave table for the map density at the initial guess (the transform k_set_state just stored);
+    // both kernels take everything from the DevCtx block, so the captured graph stays valid from scan to scan
+    hipLaunchKernelGGL(k_wave_density, dim3((sh.table_cap + 3) / 4, sh.nslots), dim3(256), 0, h->stream, sh.tbl, h->density_raw);
+    hipLaunchKernelGGL(k_chunk_table_density, dim3(1, sh.nslots), dim3(1024), 0, h->stream, sh.tbl);
 }
 
 // Launches L0 .. L1-1 of the loop.  A range that starts after launch 0 begins like launch 1 does (transform rebuilt from the
 // pose the k_finalize before it stored), and a range that ends before the last launch closes its last iteration with a
 // k_finalize of its own: with early exit on, the loop is issued in two ranges and the second only if the first did not converge.
-void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* events, bool coarse = false, int L0 = 0, int L1 = -1)
+// `events`, if given, holds 2*n events recorded around every iteration's launches; with `coarse` only four pairs are recorded - around
+// launch 0, launch 1, the run of back-to-back launches 2 .. n-2 (slots 4, 5) and launch n-1 (slots 6, 7) - so that the event
+// packets do not break up the loop's back-to-back dispatch.
+void enqueue_loop(s2m_context* h, const LoopShape& sh, hipEvent_t* events, bool coarse = false, int L0 = 0, int L1 = -1)
 {
     const int n = h->prm.max_iter;
     if (L1 < 0) L1 = n;
-    DevState* st = h->state.as<DevState>();
-    const bool fuse = h->fuse_solve && nblocks <= h->fuse_max_blocks;
-    if (h->density_raw > 0 && L0 == 0) {
-        // re-split the wave table for the map density at the initial guess (the transform k_set_state just stored);
-        // both kernels take everything from the DevCtx block, so the captured graph stays valid from scan to scan
-        hipLaunchKernelGGL(k_wave_density, dim3((h->hctx.table_cap + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
-                           h->density_raw);
-        hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, const_cast<DevCtx*>(dc), st);
-    }
+    const bool fuse = h->fuse_solve && sh.nblocks <= h->fuse_max_blocks;
+    if (h->density_raw > 0 && L0 == 0) launch_density(h, sh);
     for (int L = L0; L < L1; L++) {
         const int slot = !coarse ? 2 * L : (L == 0 ? 0 : (L == 1 ? 2 : (L == n - 1 ? 6 : 4)));
         const bool open = events && (!coarse || L <= 2 || L == n - 1), close = events && (!coarse || L <= 1 || L >= n - 2);
         if (open) (void)hipEventRecord(events[slot], h->stream);
-        launch_register(h, false, nblocks, dc, st, L, (fuse && L >= 2 && L != L0) ? 1 : 0);
+        launch_iteration(h, sh, L, (fuse && L >= 2 && L != L0) ? 1 : 0);
         if (close) (void)hipEventRecord(events[slot + 1], h->stream);
-        if (!fuse || L == 0 || L == L1 - 1) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
+        if (!fuse || L == 0 || L == L1 - 1) launch_finalize(h, sh, L, 0);
     }
 }
 
@@ -490,14 +563,14 @@ void enqueue_loop(s2m_context* h, int nblocks, const DevCtx* dc, hipEvent_t* eve
 int get_graph(s2m_context* h, int nblocks, int part, hipGraphExec_t* out)
 {
     // table_cap fixes both grids in the captured loop: k_register's (nblocks) and k_wave_density's
-    const long long key = ((long long)h->hctx.table_cap * 4 + part) * 256 + (part ? h->seg_iters : 0);
+    const LoopShape sh = shape_of(h);
+    const long long key = (((long long)h->hctx.table_cap * 4 + part) * 256 + (part ? h->seg_iters : 0)) * 4 + (sh.split ? 1 : 0) + (sh.wpb == kBigWaves ? 2 : 0);
     auto it = h->graphs.find(key);
     if (it != h->graphs.end()) { *out = it->second; return S2M_OK; }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    const DevCtx* dc = h->dctx.as<DevCtx>();
     S2M_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    enqueue_loop(h, nblocks, dc, nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
+    enqueue_loop(h, sh, nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "hipStreamEndCapture", e);
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -524,9 +597,8 @@ int launch_loop(s2m_context* h, int part = 0)
         }
         h->use_graph = false;       // capture unsupported here: fall back to plain launches
     }
-    const DevCtx* dc = h->dctx.as<DevCtx>();
     S2M_HIP(h, hipEventRecord(e0, h->stream));
-    enqueue_loop(h, nblocks, dc, nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
+    enqueue_loop(h, shape_of(h), nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(e1, h->stream));
     h->hctx.density_pending = 0;
@@ -677,6 +749,8 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_DENSITY_RAW")) h->density_raw = atoi(e);
     if (const char* e = getenv("S2M_BIG_BLOCKS")) h->big_blocks = !(e[0] == '0');
     if (const char* e = getenv("S2M_SEGMENT")) h->seg_iters = atoi(e);
+    if (const char* e = getenv("S2M_SPLIT")) h->split_mode = atoi(e);
+    if (const char* e = getenv("S2M_LOCKSTEP")) h->lockstep = !(e[0] == '0');
     h->fuse_max_blocks = kFuseMaxBlocks;
     if (const char* e = getenv("S2M_FUSE_MAX")) h->fuse_max_blocks = atoi(e);
 
@@ -697,7 +771,6 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (hipHostMalloc((void**)&h->h_sc, sizeof(double) * 1220) != hipSuccess) return bail(S2M_ERR_HIP);
     if (ensure(h, h->state, sizeof(DevState) + sizeof(s2m_iter_trace) * kMaxIter) ||      // loop state, then the trace
         ensure(h, h->dctx, sizeof(DevCtx)) || ensure(h, h->mm, 64) ||
-        ensure(h, h->partials, sizeof(double) * 2 * kAcc * kBlocksQuantum) ||
         ensure(h, h->sc_bins, sizeof(uint32_t) * 1200) || ensure(h, h->sc_out, sizeof(double) * 1220) ||
         ensure(h, h->q_counts, sizeof(int32_t) * kPolarCells))
         return bail(S2M_ERR_HIP);
@@ -709,7 +782,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     memset(&h->hctx, 0, sizeof(h->hctx));
     h->hctx.nblocks = kBlocksQuantum;
     h->hctx.wpb = kBlock / 64;
-    h->hctx.partials = h->partials.as<double>();
+    if (ensure_rows(h, kBlocksQuantum)) return bail(S2M_ERR_HIP);
     h->hctx.state = h->state.as<DevState>();
     h->hctx.trace = reinterpret_cast<s2m_iter_trace*>(h->state.as<DevState>() + 1);
     params_to_ctx(h, prm);
@@ -937,26 +1010,49 @@ int ensure_kids(s2m_context* h, int n)
     return S2M_OK;
 }
 
-// One graph for the whole batch: a fork, one branch per scan with that scan's loop (enqueue_loop), a join.
+// One graph for the whole batch.  Lockstep (default): the slots' loops advance together, every launch of the loop has one
+// grid row per slot (slots of different workgroup shape form groups, one loop per group on a branch of its own).  Otherwise
+// (S2M_LOCKSTEP=0, A/B measurements): a fork, one branch per scan with that scan's loop, a join.
 int get_batch_graph(s2m_context* h, const std::vector<int>& live, hipGraphExec_t* out)
 {
     std::vector<int> key;
-    for (int b : live) { key.push_back(b); key.push_back(h->kids[(size_t)b]->hctx.table_cap); }
+    for (int b : live) { key.push_back(b); key.push_back(h->kids[(size_t)b]->hctx.table_cap); key.push_back(h->kids[(size_t)b]->hctx.wpb); }
     auto it = h->batch_graphs.find(key);
     if (it != h->batch_graphs.end()) { *out = it->second; return S2M_OK; }
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    // the loops to run: (shape, stream to run it on)
+    std::vector<LoopShape> loops;
+    if (h->lockstep) {
+        for (int wpb : { kBlock / 64, kBigWaves }) {
+            LoopShape sh;
+            memset(&sh.tbl, 0, sizeof(sh.tbl));
+            sh.nslots = 0; sh.wpb = wpb; sh.batch = true;
+            for (int b : live) {
+                s2m_context* k = h->kids[(size_t)b];
+                if (k->hctx.wpb != wpb) continue;
+                sh.tbl.ctx[sh.nslots] = k->dctx.as<DevCtx>();
+                sh.tbl.st[sh.nslots] = k->state.as<DevState>();
+                sh.nslots++;
+                sh.nblocks = std::max(sh.nblocks, k->hctx.nblocks);
+                sh.table_cap = std::max(sh.table_cap, k->hctx.table_cap);
+            }
+            sh.split = h->split_mode != 0;
+            if (sh.nslots) loops.push_back(sh);
+        }
+    } else
+        for (int b : live) loops.push_back(shape_of(h->kids[(size_t)b]));
     S2M_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     bool ok = hipEventRecord(h->ev_fork, h->stream) == hipSuccess;
-    for (int b : live) {
-        s2m_context* k = h->kids[(size_t)b];
-        hipStream_t br = h->branch_streams[(size_t)b];
+    hipStream_t keep = h->stream;
+    for (size_t j = 0; j < loops.size(); j++) {
+        hipStream_t br = h->branch_streams[j];
         ok = ok && hipStreamWaitEvent(br, h->ev_fork, 0) == hipSuccess;
-        k->stream = br;
-        enqueue_loop(k, k->hctx.nblocks, k->dctx.as<DevCtx>(), nullptr);
-        k->stream = h->stream;
-        ok = ok && hipEventRecord(h->branch_events[(size_t)b], br) == hipSuccess;
-        ok = ok && hipStreamWaitEvent(h->stream, h->branch_events[(size_t)b], 0) == hipSuccess;
+        h->stream = br;                                       // (enqueue_loop launches on the handle's stream; settings are the parent's)
+        enqueue_loop(h, loops[j], nullptr);
+        h->stream = keep;
+        ok = ok && hipEventRecord(h->branch_events[j], br) == hipSuccess;
+        ok = ok && hipStreamWaitEvent(h->stream, h->branch_events[j], 0) == hipSuccess;
     }
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (!ok || e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "batch: stream capture failed", e);
@@ -1088,7 +1184,7 @@ int s2m_surf_optimization(s2m_handle h, const float pose[6], int32_t* idx5, floa
     h->ctx_dirty = true;
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
-    launch_register(h, true, h->hctx.nblocks, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
+    launch_fused(h, shape_of(h), true, 0, 0);
     S2M_HIP(h, hipGetLastError());
     if (idx5) S2M_HIP(h, hipMemcpyAsync(idx5, h->dbg_idx5.p, sizeof(int32_t) * 5 * n, hipMemcpyDeviceToHost, h->stream));
     if (d2_5) S2M_HIP(h, hipMemcpyAsync(d2_5, h->dbg_d2.p, sizeof(float) * 5 * n, hipMemcpyDeviceToHost, h->stream));
@@ -1116,23 +1212,19 @@ int s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint
     if (launches < 0) {
         // a real loop as enqueue_loop issues it (density re-split, R0 F0 R1 R2' ...); the recorded launch is number
         // N = -launches - 1 (N = 0: the first launch of a scan), closing the iteration before it when the loop is fused
-        const DevCtx* dc = h->dctx.as<DevCtx>(); DevState* st = h->state.as<DevState>();
+        const LoopShape sh = shape_of(h);
         const int nblocks = h->hctx.nblocks, N = -launches - 1;
         const bool fuse = h->fuse_solve && nblocks <= h->fuse_max_blocks;
-        if (h->density_raw > 0) {
-            hipLaunchKernelGGL(k_wave_density, dim3((h->hctx.table_cap + 3) / 4), dim3(256), 0, h->stream, dc, (const DevState*)st,
-                               h->density_raw);
-            hipLaunchKernelGGL(k_chunk_table_density, dim3(1), dim3(1024), 0, h->stream, const_cast<DevCtx*>(dc), st);
-        }
+        if (h->density_raw > 0) launch_density(h, sh);
         h->hctx.density_pending = 0;                      // cleared on the device by the kernel: keep the host copy in step
         for (int L = 0; L < N; L++) {
-            launch_register(h, false, nblocks, dc, st, L, (fuse && L >= 2) ? 1 : 0);
-            if (!fuse || L == 0) hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, st, L, 0);
+            launch_iteration(h, sh, L, (fuse && L >= 2) ? 1 : 0);
+            if (!fuse || L == 0) launch_finalize(h, sh, L, 0);
         }
-        launch_register(h, true, nblocks, dc, st, N, (fuse && N >= 2) ? 1 : 0);
+        launch_fused(h, sh, true, N, (fuse && N >= 2) ? 1 : 0);
     }
     for (int rep = 0; rep < launches; rep++)
-        launch_register(h, true, h->hctx.nblocks, (const DevCtx*)h->dctx.as<DevCtx>(), h->state.as<DevState>(), 0, 0);
+        launch_fused(h, shape_of(h), true, 0, 0);
     S2M_HIP(h, hipGetLastError());
     const size_t n = nwaves < cap_waves ? nwaves : cap_waves;
     S2M_HIP(h, hipMemcpyAsync(out, h->dbg_clk.p, sizeof(uint64_t) * kProfWords * n, hipMemcpyDeviceToHost, h->stream));
@@ -1176,9 +1268,11 @@ int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6]
     int rc;
     if ((rc = upload_ctx(h))) return rc;
     if ((rc = push_state(h, pose))) return rc;
-    const DevCtx* dc = h->dctx.as<DevCtx>();
-    launch_register(h, false, h->hctx.nblocks, dc, h->state.as<DevState>(), 0, 0);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinThreads), 0, h->stream, dc, h->state.as<DevState>(), 0, 1);
+    {
+        const LoopShape sh = shape_of(h);
+        launch_fused(h, sh, false, 0, 0);
+        launch_finalize(h, sh, 0, 1);
+    }
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState), hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
@@ -1210,7 +1304,6 @@ static int time_iterations_impl(s2m_handle h, const float pose[6], int reps, flo
     S2M_HIP(h, hipSetDevice(h->device));
     int rc;
     if ((rc = upload_ctx(h))) return rc;
-    const DevCtx* dc = h->dctx.as<DevCtx>();
     const int nit = h->prm.max_iter;
     if (h->iter_events.size() < (size_t)(2 * nit)) {
         const size_t old = h->iter_events.size();
@@ -1223,7 +1316,7 @@ static int time_iterations_impl(s2m_handle h, const float pose[6], int reps, flo
         S2M_HIP(h, hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream));
         S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int4) * h->n_q, h->stream));
         if ((rc = push_state(h, pose))) return rc;
-        enqueue_loop(h, h->hctx.nblocks, dc, h->iter_events.data());     // the real loop, launched one by one between event pairs
+        enqueue_loop(h, shape_of(h), h->iter_events.data());     // the real loop, launched one by one between event pairs
         h->hctx.density_pending = 0;
         S2M_HIP(h, hipGetLastError());
         S2M_HIP(h, hipStreamSynchronize(h->stream));
@@ -1256,11 +1349,11 @@ int s2m_debug_time_steady(s2m_handle h, const float pose[6], int reps, int solve
     int rc = s2m_optimize_resident(h, p, nullptr, &r);
     if (rc) return rc;
     if (r.skipped || r.iters_run != h->prm.max_iter) return fail(h, S2M_ERR_INVALID_ARG, "the loop ended early: switch early_exit off");
-    const DevCtx* dc = h->dctx.as<DevCtx>();
+    const LoopShape sh = shape_of(h);
     const int L = h->prm.max_iter;
     S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
     for (int k = 0; k < reps; k++)
-        launch_register(h, false, h->hctx.nblocks, dc, h->state.as<DevState>(), L, solve_prev ? 1 : 0);
+        launch_iteration(h, sh, sh.split ? L + (k & 1) : L, solve_prev ? 1 : 0);   // (split: the worklist slots alternate with the launch parity)
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
@@ -1282,13 +1375,12 @@ int s2m_time_loop_launches(s2m_handle h, const float pose[6], int reps, float* u
     int rc;
     if ((rc = upload_ctx(h))) return rc;
     while (h->iter_events.size() < 8) { hipEvent_t e; S2M_HIP(h, hipEventCreate(&e)); h->iter_events.push_back(e); }
-    const DevCtx* dc = h->dctx.as<DevCtx>();
     double total_ms = 0.0;
     for (int rep = 0; rep < reps; rep++) {
         S2M_HIP(h, hipMemsetAsync(h->cert.p, 0, sizeof(float4) * h->n_q, h->stream));      // a new scan: no certificates, no neighbourhoods
         S2M_HIP(h, hipMemsetAsync(h->aux.p, 0, sizeof(int4) * h->n_q, h->stream));
         if ((rc = push_state(h, pose))) return rc;
-        enqueue_loop(h, h->hctx.nblocks, dc, h->iter_events.data(), true);
+        enqueue_loop(h, shape_of(h), h->iter_events.data(), true);
         h->hctx.density_pending = 0;
         S2M_HIP(h, hipGetLastError());
         S2M_HIP(h, hipStreamSynchronize(h->stream));

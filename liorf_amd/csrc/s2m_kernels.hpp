@@ -627,8 +627,10 @@ __global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict_
 }
 
 // per scan before launch 0, inside the captured loop: everything comes from the DevCtx block
-__global__ __launch_bounds__(1024) void k_chunk_table_density(DevCtx* __restrict__ cp, DevState* __restrict__ st)
+__global__ __launch_bounds__(1024) void k_chunk_table_density(const SlotTable tbl)
 {
+    DevCtx* __restrict__ cp = const_cast<DevCtx*>(tbl.ctx[blockIdx.y]);
+    DevState* __restrict__ st = tbl.st[blockIdx.y];
     if (!cp->density_pending) return;                     // once per scan (the flag is uniform: read before the barrier below)
     __syncthreads();
     if (threadIdx.x == 0) cp->density_pending = 0;
@@ -1293,9 +1295,10 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
 // k_chunk_table_density rebuilds the table.  Partition only: results do not depend on it beyond the
 // summation order of the normal equations.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_wave_density(const DevCtx* __restrict__ cp, const DevState* __restrict__ state, int raw_limit)
+__global__ __launch_bounds__(256) void k_wave_density(const SlotTable tbl, int raw_limit)
 {
-    const auto st = G(state);
+    const DevCtx* __restrict__ cp = tbl.ctx[blockIdx.y];
+    const auto st = G((const DevState*)tbl.st[blockIdx.y]);
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (!cp->density_pending || wv >= st->n_waves) return;   // the table of a scan is re-split once, at its first optimisation
@@ -1341,9 +1344,10 @@ __global__ __launch_bounds__(256) void k_wave_density(const DevCtx* __restrict__
 // iteration 0 with the degeneracy analysis, and the last iteration of a scan (or every iteration
 // when the grid is too large for the fused form).  mode 1 = normal equations only (observation hook).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kFinThreads) void k_finalize(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int iter, int mode)
+__global__ __launch_bounds__(kFinThreads) void k_finalize(const SlotTable tbl, int iter, int mode)
 {
-    const auto st = G(state);
+    const DevCtx* __restrict__ cp = tbl.ctx[blockIdx.y];
+    const auto st = G(tbl.st[blockIdx.y]);
     // loop state, fetched up front (the state block is a kernel argument: no pointer chase through DevCtx)
     const int done0 = st->done, degen0 = st->isDegenerate;
     const int nb_act = (st->n_waves + cp->wpb - 1) / cp->wpb;

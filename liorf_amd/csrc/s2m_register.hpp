@@ -1007,35 +1007,129 @@ __device__ __forceinline__ void linearise_chunk(const DevCtx* __restrict__ cp, c
     linearise_point<HOOK>(cp, T, sc6, i, px, py, pz, pl, acc);
 }
 
-// NW waves per workgroup; MINW waves per SIMD the kernel is built for: 2 (256 registers per lane, no scratch: a single scan up to
-// 2 048 waves has one 8-wave workgroup per CU anyway) or 4 (128 registers: two 8-wave workgroups per CU for batches of scans, or
-// one 16-wave workgroup for large scans)
-template <bool HOOK, int NW, int MINW>
-__global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __restrict__ cp, DevState* __restrict__ state, int launch, int solve_prev)
+// ------------------------------------------------------------------------------------------
+// The registration kernels.  One source, three roles (MODE):
+//
+//   kFused    R  one launch = the whole iteration: certificate test, association of the lanes that fail it (tiers B / C) in
+//                line, residuals, partial row; with solve_prev its prologue closes the iteration before.  The kernel of a
+//                single small scan, where nothing else wants the CU and a second kernel per iteration only adds a boundary.
+//   kCertify  C  the same without tiers B / C: no tile, no candidate lists, a quarter of the registers.  A workgroup in
+//                which some lane needs more than its certificate (and is not settled by the in-line re-measurement) writes
+//                NO partial row: it puts its number on the launch's worklist and ...
+//   kSearch   S  ... one workgroup of the search kernel per worklist entry does that workgroup's iteration again, association
+//                included, with a register budget of its own, and writes the row.  With kAll set (launch 0 of a scan: nothing
+//                is certified yet) every workgroup is "on the list" and no C launch precedes it.
+//
+// Which kernel writes a workgroup's row makes no difference to the row: the row of workgroup b is always
+//   sum over its CNW waves w, in order, of ( lane tree ( sum over the wave's entries, in order, of the lane's 28 products ) ),
+// computed by the same functions below (wave_reduce_acc, write_partial_row) - so a loop gives bitwise the same trace
+// whether its lanes were certified, re-measured or searched, in one kernel or in two (tests/test_tiers_gpu.py).
+//
+// Several scans at once (s2m_optimize_batch): blockIdx.y selects the scan slot; the slots' loops advance in lockstep, one
+// launch per iteration for all of them.
+// ------------------------------------------------------------------------------------------
+constexpr int kFused = 0, kCertify = 1, kSearch = 2;
+constexpr int kCertifyWaves = 4;       // waves per SIMD the certify kernel is built for (8-wave workgroups) ...
+constexpr int kCertifyWavesBig = 4;    // ... and in the 16-wave shape of large scans
+constexpr int kFlagSolvePrev = 1;      // the prologue closes iteration launch-1 (fused loop)
+constexpr int kFlagAll = 2;            // kSearch: every workgroup, no worklist (launch 0 of a scan, observation hooks)
+// ---- wave reduction by recursive halving: at mask m a lane keeps one half of its sums and
+// hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
+// five steps lane l holds, in a[0], sum number l>>1 over its half-wave pair group, and one
+// full exchange with lane^1 completes it.  Fixed order: bitwise reproducible.
+__device__ __forceinline__ void wave_reduce_acc(const double (&acc)[kAcc], int lane, double* red_row /* [32] of this wave */)
 {
-    // The loop state block never moves, so it comes as a kernel argument: `done` and the wave count arrive
+    double a[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) a[k] = (k < kAcc) ? acc[k] : 0.0;
+#pragma unroll
+    for (int h = 16, m = 32; h >= 1; h >>= 1, m >>= 1) {
+        const bool up = (lane & m) != 0;
+#pragma unroll
+        for (int j = 0; j < h; j++) {
+            const double keepv = up ? a[j + h] : a[j];
+            const double sendv = up ? a[j] : a[j + h];
+            a[j] = keepv + __shfl_xor(sendv, m, 64);
+        }
+    }
+    a[0] += __shfl_xor(a[0], 1, 64);
+    if ((lane & 1) == 0) red_row[lane >> 1] = a[0];
+}
+
+// the workgroup's partial row: the sums of its CNW waves, in wave order (after a barrier)
+template <int CNW>
+__device__ __forceinline__ void write_partial_row(const DevCtx* __restrict__ cp, int launch, int b, int tid, const double (*red)[32])
+{
+    if (tid < kAcc) {
+        const auto partial_row = G(cp->partials) + ((size_t)(launch & 1) * (size_t)cp->nblocks + b) * kAcc;   // slot launch & 1
+        double s = red[0][tid];
+#pragma unroll
+        for (int w = 1; w < CNW; w++) s += red[w][tid];
+        partial_row[tid] = s;
+    }
+}
+
+// the certificate test of one lane at this pose (tier A)
+__device__ __forceinline__ bool lane_needs(const float (&T)[12], float px, float py, float pz, const v4f cert, bool valid, int ablate,
+                                           float& sx, float& sy, float& sz, float& eps)
+{
+    sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
+    sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
+    sz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
+    const bool fin = valid && (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
+    const float ex = sx - cert.x, ey = sy - cert.y, ez = sz - cert.z;
+    eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
+    return fin && !(!(ablate & 1) && (eps < cert.w));
+}
+
+// NW waves per workgroup; MINW waves per SIMD the kernel is built for (the register budget: 512 / MINW per lane);
+// CNW: waves per workgroup of the partition whose rows this kernel writes (kSearch: the C kernel's shape; otherwise NW)
+template <bool HOOK, int NW, int MINW, int MODE, int CNW = NW>
+__global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl, int launch, int flags)
+{
+    static_assert(MODE == kSearch || CNW == NW, "only the search kernel works on another kernel's partition");
+    static_assert(CNW % NW == 0, "a search workgroup takes the waves of a row in whole rounds");
+    static_assert(!(HOOK && MODE == kCertify), "the observation hook needs the association in line");
+    const DevCtx* __restrict__ cp = tbl.ctx[blockIdx.y];
+    // The loop state block never moves, so it comes with the kernel arguments: `done` and the wave count arrive
     // with the first round trip, in parallel with the DevCtx block, instead of behind a pointer chase.
-    const auto st = G(state);
+    const auto st = G(tbl.st[blockIdx.y]);
     const int done = st->done, n_waves = st->n_waves;
     if (!HOOK && done) return;
+    const bool solve_prev = MODE != kSearch && (flags & kFlagSolvePrev) != 0;
     unsigned long long tk_start = 0, clk1 = 0, clk2 = 0;
     unsigned long long lm_stamps[7] = { 0, 0, 0, 0, 0, 0, 0 };   // diagnostics of the fused LM close
     if (HOOK) tk_start = wall_clock64();
 
-    __shared__ v4f     s_pts[NW][kTilePts];          // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
+    constexpr bool kHasSearch = MODE != kCertify;
+    constexpr int  kTileWaves = kHasSearch ? NW : 1;
+    __shared__ v4f     s_pts[kTileWaves][kHasSearch ? kTilePts : 1];   // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
     static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
-    __shared__ double  red[NW][32];
-    __shared__ uint16_t s_cand[NW][kCand * 64];     // per wave: tile positions of each lane's candidates, [k][lane]
-    __shared__ int2    s_rows[NW][64];              // per wave: the non-empty box rows of the current row group
+    __shared__ double  red[CNW][32];
+    __shared__ uint16_t s_cand[kTileWaves][kHasSearch ? kCand * 64 : 1];   // per wave: tile positions of each lane's candidates, [k][lane]
+    __shared__ int2    s_rows[kTileWaves][kHasSearch ? 64 : 1];            // per wave: the non-empty box rows of the current row group
     __shared__ float   s_lm_out[8];                  // pose + loop-ended flag published by lm_close_iteration
+    __shared__ LmShared s_lm;                        // (kCertify: the close has no tile area to borrow)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblocks = cp->nblocks;
+    const int nb_act = min((n_waves + CNW - 1) / CNW, nblocks);            // workgroups the wave table needs
+    // ---- which row of the partition this workgroup works on
+    int b = (int)blockIdx.x;
+    if (MODE == kSearch && !(flags & kFlagAll)) {
+        const auto wlc = G(cp->wl_count);
+        const int cnt = wlc[launch & 1];
+        if (b == 0 && tid == 0) wlc[(launch + 1) & 1] = 0;                  // the next launch's list starts empty (nobody reads or appends to it now)
+        if (b >= cnt) return;
+        b = __builtin_amdgcn_readfirstlane(G(cp->wl_items)[(size_t)(launch & 1) * (size_t)nblocks + b]);
+    } else if (MODE == kSearch) {
+        if (b == 0 && tid == 0) G(cp->wl_count)[(launch + 1) & 1] = 0;
+    }
+    if (b >= nb_act) return;                                                // the rest of the (fixed, graph-captured) grid idles
     // Wave w of workgroup b starts at entry w*nb_act + b of the wave table and advances by the number of waves in
-    // the grid: neighbouring entries (similar cost: the sort runs from the dense near field to the sparse far
+    // the partition: neighbouring entries (similar cost: the sort runs from the dense near field to the sparse far
     // field) land on different CUs, which evens out both the work and the L2-miss queues.
-    const int nb_act = min((n_waves + NW - 1) / NW, (int)gridDim.x);       // workgroups the wave table needs
-    if ((int)blockIdx.x >= nb_act) return;                                  // the rest of the (fixed, graph-captured) grid idles
-    const int e0 = wave * nb_act + (int)blockIdx.x, estride = nb_act * NW;
+    const int estride = nb_act * CNW;
     const auto tb = G((const int2*)cp->wave_table);
     const int nq = cp->n_q;
     const GridDesc g = cp->g;
@@ -1046,6 +1140,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
 
     // everything of the first entry that does not depend on the pose is requested first: it is in flight while the
     // previous iteration is closed below
+    int e0 = wave * nb_act + b;
     int2 chunk = make_int2(0, 0);
     if (e0 < n_waves) { chunk.x = tb[e0].x; chunk.y = tb[e0].y; }
     chunk.x = __builtin_amdgcn_readfirstlane(chunk.x);       // wave-uniform: scalar registers
@@ -1063,7 +1158,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
     // transPointAssociateToMap (:1069-1072) and the LM trig (:1170-1175). Launch 0 of a scan gets them
     // from the host (libm); later launches rebuild them from the pose: lanes 0..2 take one angle each
     // (glibc's sinf / cosf arithmetic, see glibc_sincosf).  With solve_prev the pose is first advanced by closing
-    // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.
+    // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.  The search kernel takes
+    // what the certify kernel of the same launch left in the state block.
     Fragile frag;
 #pragma unroll
     for (int k = 0; k < 6; k++) frag.mm[k] = v3f{ 0.0f, 0.0f, 0.0f };
@@ -1073,11 +1169,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
         for (int k = 0; k < 12; k++) T[k] = st->T[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) sc6[k] = st->sc[k];
+    } else if (MODE == kSearch) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = st->T2[launch & 1][k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sc6[k] = st->sc2[launch & 1][k];
     } else {
         float pose[6];
         if (solve_prev) {
-            static_assert(sizeof(LmShared) <= sizeof(v4f) * kTilePts * NW, "LM scratch must fit the tile area");
-            LmShared& sh = *reinterpret_cast<LmShared*>(&s_pts[0][0]);
+            static_assert(MODE == kCertify || sizeof(LmShared) <= sizeof(v4f) * kTilePts * NW, "LM scratch must fit the tile area");
+            LmShared& sh = (MODE == kCertify) ? s_lm : *reinterpret_cast<LmShared*>(&s_pts[0][0]);
             const int degen0 = st->isDegenerate;
             float pose0[6];
 #pragma unroll
@@ -1124,6 +1225,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
         T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = pose[4];
         T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = pose[5];
         sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
+        if (MODE == kCertify && blockIdx.x == 0 && tid == 0) {                      // for the search kernel of this launch
+#pragma unroll
+            for (int k = 0; k < 12; k++) st->T2[launch & 1][k] = T[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) st->sc2[launch & 1][k] = sc6[k];
+        }
     }
     // wave-uniform by construction: into scalar registers, out of the way of everything below
 #pragma unroll
@@ -1134,17 +1241,41 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
 
     WaveProf prof;
     double acc[kAcc];                                       // zeroed only after the association: nothing of pass 2 is live during pass 1
+    bool defer = false;                                     // kCertify: this wave holds a lane that needs the search kernel
+
+    if (MODE == kSearch) {
+        // ---- the search kernel: the waves of row b in rounds of NW; per wave the association of all its entries, then the residuals
+        for (int r = 0; r < CNW / NW; r++) {
+            const int w = r * NW + wave;
+            e0 = w * nb_act + b;
+            for (int e = e0; e < n_waves; e += estride) {
+                if (r != 0 || e != e0) {
+                    chunk = make_int2(__builtin_amdgcn_readfirstlane(tb[e].x), __builtin_amdgcn_readfirstlane(tb[e].y));
+                    px = 0.0f; py = 0.0f; pz = 0.0f; cert = v4f{ 0, 0, 0, 0 };
+                    if (lane < chunk.y && chunk.x + lane < nq) {
+                        const int i = chunk.x + lane;
+                        px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];
+                        cert = G((const v4f*)cp->cert)[i];
+                    }
+                }
+                associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
+                                      px, py, pz, cert, prof);
+            }
+            if (HOOK) clk1 = wall_clock64();
+#pragma unroll
+            for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+            for (int e = e0; e < n_waves; e += estride)
+                linearise_chunk<HOOK>(cp, T, sc6, make_int2(tb[e].x, tb[e].y), lane, acc);
+            wave_reduce_acc(acc, lane, red[w]);
+        }
+        if (HOOK) clk2 = wall_clock64();
+    } else {
     const bool single = e0 + estride >= n_waves;            // one entry for this wave (every scan up to 262 144 points): its point stays in registers
     if (__builtin_expect(single, 1)) {
         if (e0 < n_waves) {
             // the certificate test of associate_chunk, up front: a fully certified entry goes straight to its residuals
-            const float sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
-            const float sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
-            const float sz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
-            const bool fin = valid0 && (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
-            const float ex = sx - cert.x, ey = sy - cert.y, ez = sz - cert.z;
-            const float eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
-            const bool need = fin && !(!(ablate & 1) && (eps < cert.w));
+            float sx, sy, sz, eps;
+            const bool need = lane_needs(T, px, py, pz, cert, valid0, ablate, sx, sy, sz, eps);
             // Lanes without slack (a near-tie between two neighbour distances) fail that test in every launch, however small the
             // step, and the wave that holds one would go through the association - a long way off in the instruction stream -
             // while every other wave of the launch is done.  What such a lane needs has been fetched behind the close (frag):
@@ -1230,7 +1361,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
                     G((v4i*)cp->aux)[i] = anew;
                 }
             }
-            if (HOOK || __builtin_expect(__ballot(need) != 0ull && !quick, 0)) {     // (unlikely: the search is laid out away from the certified path)
+            if (MODE == kCertify) {
+                defer = __ballot(need) != 0ull && !quick;                            // this workgroup's row is the search kernel's business
+            } else if (HOOK || __builtin_expect(__ballot(need) != 0ull && !quick, 0)) {     // (unlikely: the search is laid out away from the certified path)
                 associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
                                       px, py, pz, cert, prof);
                 // The point is read again (L2-warm) rather than kept in registers through the association: what the
@@ -1246,7 +1379,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
             if (HOOK) clk1 = wall_clock64();
 #pragma unroll
             for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
-            if (valid0) linearise_point<HOOK>(cp, T, sc6, chunk.x + lane, px, py, pz, plane0, acc);
+            if (valid0 && !defer) linearise_point<HOOK>(cp, T, sc6, chunk.x + lane, px, py, pz, plane0, acc);
         } else {
 #pragma unroll
             for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
@@ -1263,17 +1396,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
             if (lane < en.y && i < nq) {
                 const float qx = G(cp->qx)[i], qy = G(cp->qy)[i], qz = G(cp->qz)[i];
                 const v4f ce = G((const v4f*)cp->cert)[i];
-                const float sx = ((T[0] * qx + T[1] * qy) + T[2]  * qz) + T[3];
-                const float sy = ((T[4] * qx + T[5] * qy) + T[6]  * qz) + T[7];
-                const float sz = ((T[8] * qx + T[9] * qy) + T[10] * qz) + T[11];
-                const bool fin = (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
-                const float ex = sx - ce.x, ey = sy - ce.y, ez = sz - ce.z;
-                const float eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
-                need = fin && !(!(ablate & 1) && (eps < ce.w));
+                float sx, sy, sz, eps;
+                need = lane_needs(T, qx, qy, qz, ce, true, ablate, sx, sy, sz, eps);
             }
             any_need = any_need || (__ballot(need) != 0ull);
         }
     }
+    if (MODE == kCertify) defer = any_need;
+    else {
     // ---- pass 1: associate
     if (__builtin_expect(any_need, 0))
     for (int e = e0; e < n_waves; e += estride) {
@@ -1289,36 +1419,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
         associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
                               px, py, pz, cert, prof);
     }
+    }
     if (HOOK) clk1 = wall_clock64();
 
     // ---- pass 2: linearise
 #pragma unroll
     for (int k = 0; k < kAcc; k++) acc[k] = 0.0;
+    if (!defer)
     for (int e = e0; e < n_waves; e += estride)
         linearise_chunk<HOOK>(cp, T, sc6, make_int2(tb[e].x, tb[e].y), lane, acc);
     }
     if (HOOK) clk2 = wall_clock64();
-
-    // ---- wave reduction by recursive halving: at mask m a lane keeps one half of its sums and
-    // hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
-    // five steps lane l holds, in a[0], sum number l>>1 over its half-wave pair group, and one
-    // full exchange with lane^1 completes it.  Fixed order: bitwise reproducible.
-    const auto partial_row = G(cp->partials) + ((size_t)(launch & 1) * (size_t)cp->nblocks + blockIdx.x) * kAcc;   // slot launch & 1
-    double a[32];
-#pragma unroll
-    for (int k = 0; k < 32; k++) a[k] = (k < kAcc) ? acc[k] : 0.0;
-#pragma unroll
-    for (int h = 16, m = 32; h >= 1; h >>= 1, m >>= 1) {
-        const bool up = (lane & m) != 0;
-#pragma unroll
-        for (int j = 0; j < h; j++) {
-            const double keepv = up ? a[j + h] : a[j];
-            const double sendv = up ? a[j] : a[j + h];
-            a[j] = keepv + __shfl_xor(sendv, m, 64);
-        }
+    wave_reduce_acc(acc, lane, red[wave]);
     }
-    a[0] += __shfl_xor(a[0], 1, 64);
-    if ((lane & 1) == 0) red[wave][lane >> 1] = a[0];
+
     if (HOOK && cp->dbg_clk && lane == 0) {
         const auto d = G(cp->dbg_clk) + kProfWords * ((size_t)blockIdx.x * NW + wave);
         d[0] = tk_start; d[1] = clk1; d[2] = clk2; d[3] = wall_clock64();
@@ -1329,12 +1443,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const DevCtx* __rest
         d[16] = lm_stamps[5]; d[17] = lm_stamps[0]; d[18] = lm_stamps[1]; d[19] = lm_stamps[2]; d[20] = lm_stamps[3]; d[21] = lm_stamps[4]; d[22] = lm_stamps[6]; d[23] = prof.ts[3];
         d[24] = (unsigned long long)prof.n_fb; d[25] = (unsigned long long)prof.reach_mm; d[26] = (unsigned long long)prof.kq; d[27] = (unsigned long long)prof.cmax;
     }
-    __syncthreads();
-    if (tid < kAcc) {
-        double s = red[0][tid];
-#pragma unroll
-        for (int w = 1; w < NW; w++) s += red[w][tid];
-        partial_row[tid] = s;
-    }
+    if (MODE == kCertify) {
+        // one lane that needs the search kernel sends the whole workgroup there: its row has to come out of one summation
+        if (__syncthreads_or(defer ? 1 : 0)) {
+            if (tid == 0) {
+                const int slot = atomicAdd(cp->wl_count + (launch & 1), 1);
+                G(cp->wl_items)[(size_t)(launch & 1) * (size_t)nblocks + slot] = b;
+            }
+            return;
+        }
+    } else
+        __syncthreads();
+    write_partial_row<CNW>(cp, launch, b, tid, red);
 }
-

@@ -46,6 +46,8 @@ struct DevState {
     int32_t stalled;      // n_sel < min_corr: every further iteration is the same no-op
     int32_t n_waves;      // wave-table entries of the resident scan (copied in by k_set_state)
     int32_t T_valid;      // 1: T/sc were set by the host (launch 0); 0: k_register rebuilds them from pose2
+    float T2[2][12];      // what the certify kernel of launch L built from pose2[L & 1], for the search kernel of the same launch
+    float sc2[2][6];
 };
 
 // Everything a kernel needs, in device memory so a captured graph stays valid when
@@ -80,6 +82,8 @@ struct DevCtx {
     int32_t  n_chunks;
     int32_t  density_pending;     // 1 from s2m_set_scan until the scan's first optimisation has re-split the table
     double* partials;             // [2][nblocks][kAcc], slot = launch parity
+    int32_t* wl_count;            // [2] worklist of the search kernel, slot = launch parity: workgroups of the certify kernel that wrote no row ...
+    int32_t* wl_items;            // [2][nblocks] ... and their numbers
     DevState* state;
     s2m_iter_trace* trace;        // [kMaxIter]
     // parameters
@@ -92,6 +96,14 @@ struct DevCtx {
     // observation outputs of the hook variant (original scan order), may be null
     int32_t* dbg_idx5; float* dbg_d2; uint8_t* dbg_flag; float* dbg_coeff;
     unsigned long long* dbg_clk;  // [nwaves][kProfWords] per-wave wall-clock stamps + tile stats (diagnostics)
+};
+
+// The registration kernels take their scans by slot: blockIdx.y selects one (a single scan: one slot).  A batch of scans
+// advances in lockstep - one launch per iteration for all slots.
+constexpr int kMaxSlots = 64;          // scan slots of a batch (include/liorf_s2m.h: n_scans <= 64)
+struct SlotTable {
+    const DevCtx* ctx[kMaxSlots];
+    DevState*     st[kMaxSlots];
 };
 
 }  // namespace s2m
