@@ -153,8 +153,9 @@ int  s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu,
  * The reference registers one scan at a time (laserCloudInfoHandler holds `mtx`, :252); scans of a batch share nothing but the
  * read-only local map, so n_scans scan2MapOptimization() calls can be in flight at once: every scan
  * slot has its own buffers, loop state and trace, all slots search the map installed with s2m_set_map / s2m_extract_cloud on
- * `h`, and the n_scans LM loops run as parallel branches of ONE captured graph (one launch, one synchronisation).  While
- * one scan's loop waits on the few-microsecond serial chain that closes an LM iteration, the others' points are processed.
+ * `h`, and the n_scans LM loops advance in lockstep inside ONE captured graph (one launch, one synchronisation): every kernel
+ * launch of the loop carries one grid row per scan, so that while one scan's workgroups wait on a dependent load the others'
+ * points are processed.
  * Results are those of n_scans separate s2m_optimize calls, bit for bit.
  *   scans[b], sizes[b]    laserCloudSurfLastDS of scan b (host records, stride_bytes as everywhere)
  *   poses[6*b .. 6*b+5]   in: initial guess of scan b, out: its transformTobeMapped
@@ -164,6 +165,9 @@ int  s2m_optimize_batch(s2m_handle h, int n_scans, const void* const* scans, con
 /* The same in steps: install scan b in slot b (host or device records; a device source must stay valid until the collect),
  * enqueue the batch without synchronising, synchronise and fetch. */
 int  s2m_batch_set_scan(s2m_handle h, int slot, const void* pts, size_t n, size_t stride_bytes, int on_device);
+/* All slots 0 .. n_scans-1 at once: the ordering kernels of the n_scans scans share their launches (six launches for the batch
+ * instead of six per scan; the host side of a batch of eight scans is otherwise a quarter of its wall time). */
+int  s2m_batch_set_scans(s2m_handle h, int n_scans, const void* const* scans, const size_t* sizes, size_t stride_bytes, int on_device);
 int  s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses);
 int  s2m_optimize_batch_collect(s2m_handle h, int n_scans, float* poses, const s2m_imu_init* imu, s2m_result* out);
 int  s2m_batch_get_trace(s2m_handle h, int slot, s2m_iter_trace* out, int cap);

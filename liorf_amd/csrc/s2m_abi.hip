@@ -82,7 +82,13 @@ struct s2m_context {
     std::vector<s2m_context*> kids;
     std::vector<hipStream_t> branch_streams;
     std::vector<hipEvent_t> branch_events;
-    hipEvent_t ev_fork = nullptr;
+    std::vector<hipEvent_t> prep_events;  // a slot's scan preparation runs on the slot's branch stream, next to the other slots': done when this fires
+    std::vector<char> prep_pending;
+    hipEvent_t ev_fork = nullptr, ev_prep = nullptr;
+    // loop state + trace of every slot in one block (device) with a pinned mirror: one copy brings all of a batch's results back
+    DevBuf kid_states;
+    unsigned char* h_kid_states = nullptr;
+    bool state_borrowed = false;       // (a slot: `state` and `h_state` point into the parent's blocks)
     std::map<std::vector<int>, hipGraphExec_t> batch_graphs;
     unsigned long long map_epoch = 0;     // bumped by every s2m_set_map: children re-adopt the index when it changed
     unsigned long long adopted_epoch = 0;
@@ -100,6 +106,8 @@ struct s2m_context {
     hipEvent_t ev_a2 = nullptr, ev_b2 = nullptr;
     int  split_mode = -1;              // env S2M_SPLIT: 1 = every loop runs certify + search kernels, 0 = every loop the fused kernel, default: split for the
                                        // scan slots of a batch and for 16-wave workgroups (large scans), fused for a single small scan
+    int  batch_entries = 1;            // env S2M_BATCH_ENTRIES: wave-table entries per wave in the scan slots of a batch (fewer, longer-running workgroups)
+    int  batch_minw = 4;               // env S2M_BATCH_MINW=4: the search / fused kernel of batch slots in the 128-register build
     bool lockstep = true;              // env S2M_LOCKSTEP=0: the scans of a batch as parallel branches of the graph instead of one grid row each (A/B measurements)
     bool big_blocks = true;            // env S2M_BIG_BLOCKS=0: 8-wave workgroups whatever the scan size (A/B measurements)
     int density_raw = 320;             // box points above which a wave asks for a finer cut (env S2M_DENSITY_RAW, 0 = off)
@@ -303,12 +311,15 @@ int set_map_build(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     return S2M_OK;
 }
 
-int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool on_device)
+// s2m_set_scan in three steps, so that the scan slots of a batch share the launches of the middle one:
+//   scan_slot_prepare   host side: sizes, buffers, the upload of a host source, the DevCtx fields - and the slot's row of the table
+//   launch_scan_prep    the six ordering kernels, one grid row per slot (blockIdx.y)
+//   scan_slot_finish    bookkeeping
+int scan_slot_prepare(s2m_context* h, const void* pts, size_t n, size_t stride, bool on_device, PrepSlot* ps)
 {
     int rc = check_records(h, pts, n, stride);
     if (rc) return rc;
-    S2M_HIP(h, hipSetDevice(h->device));
-    S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
+    memset(ps, 0, sizeof(*ps));
     h->n_q = n; h->have_scan = true;
     h->hctx.n_q = (int32_t)n;
     // wave table capacity: every 64-point chunk plus a 50 % budget of extra waves for split chunks
@@ -328,19 +339,20 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     // per SIMD: 256 registers per lane, no scratch; the scan slots of a batch run the 128-register build, two per CU) - and waves
     // loop over the table
     nblocks = std::min((table_cap + wpb - 1) / wpb, (wpb == NW && h->parent) ? kMaxBlocks : kMaxBlocks / 2);
+    if (h->parent && h->batch_entries > 1) nblocks = std::max((nblocks + h->batch_entries - 1) / h->batch_entries, 1);   // a batch slot: several entries per wave
     h->hctx.wpb = wpb;
     h->hctx.nblocks = nblocks;
     h->hctx.table_cap = table_cap;
     h->ctx_dirty = true;
     if ((rc = ensure_rows(h, nblocks))) return rc;
-    if (n == 0) { h->t_set_scan_ms = 0; h->scan_timing_pending = false; return upload_ctx(h); }
+    if (n == 0) return S2M_OK;
 
     const unsigned char* d_pts;
     if (on_device) d_pts = static_cast<const unsigned char*>(pts);
     else {
         if ((rc = ensure(h, h->raw_scan, n * stride))) return rc;
         S2M_HIP(h, hipMemcpyAsync(h->raw_scan.p, pts, n * stride, hipMemcpyHostToDevice, h->stream));
-        S2M_HIP(h, hipEventRecord(h->ev_up, h->stream));   // waited for below: the caller's buffer is free when this call returns
+        S2M_HIP(h, hipEventRecord(h->ev_up, h->stream));   // waited for in scan_slot_finish: the caller's buffer is free when the call returns
         d_pts = h->raw_scan.as<unsigned char>();
     }
     // locality order of the scan: log-polar Z-order bins (k_polar_count), no host round trip
@@ -358,49 +370,35 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
     if ((rc = ensure(h, h->q_rank_of, sizeof(int32_t) * n))) return rc;
-
-    const int nb = ((int)n + 255) / 256;
     const int npb = ((int)n + kPolarBlock - 1) / kPolarBlock;
     if ((rc = ensure(h, h->q_block_hist, sizeof(int32_t) * (size_t)kPolarCells * (size_t)npb))) return rc;
-    hipLaunchKernelGGL(k_polar_count, dim3(npb), dim3(kPolarBlock), 0, h->stream, d_pts, stride, (int)n,
-                       h->q_cell_of.as<int32_t>(), h->q_rank_of.as<int32_t>(), h->q_block_hist.as<int32_t>());
-    hipLaunchKernelGGL(k_polar_prefix, dim3(kPolarCells / 64), dim3(1024), 0, h->stream, h->q_block_hist.as<int32_t>(), npb,
-                       h->q_counts.as<int32_t>());
-    hipLaunchKernelGGL(k_polar_scan, dim3(1), dim3(1024), 0, h->stream,
-                       h->q_counts.as<int32_t>(), h->q_cell_start.as<int32_t>());
-    hipLaunchKernelGGL(k_scatter_scan, dim3(nb), dim3(256), 0, h->stream, d_pts, stride, (int)n,
-                       (const int32_t*)h->q_cell_of.as<int32_t>(), (const int32_t*)h->q_rank_of.as<int32_t>(),
-                       (const int32_t*)h->q_cell_start.as<int32_t>(), (const int32_t*)h->q_block_hist.as<int32_t>(),
-                       h->qx.as<float>(), h->qy.as<float>(), h->qz.as<float>(), h->qperm.as<int32_t>(),
-                       h->cert.as<float4>(), h->aux.as<int4>());
-    S2M_HIP(h, hipGetLastError());
+    if ((rc = ensure(h, h->chunk_parts, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
+    {   // density wishes: all zero between uses (k_chunk_table_density clears what it consumes)
+        const void* before = h->chunk_factor.p;
+        if ((rc = ensure(h, h->chunk_factor, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
+        if (h->chunk_factor.p != before) S2M_HIP(h, hipMemsetAsync(h->chunk_factor.p, 0, h->chunk_factor.cap, h->stream));
+    }
+    if ((rc = ensure(h, h->wave_table, sizeof(int2) * (size_t)table_cap))) return rc;
+    if ((rc = ensure(h, h->n_waves, 64))) return rc;
+
+    ps->pts = d_pts; ps->stride = stride; ps->n = (int32_t)n; ps->n_chunks = n_chunks; ps->base_parts = base_parts;
+    ps->capacity = table_cap; ps->npb = npb;
+    ps->cell_of = h->q_cell_of.as<int32_t>(); ps->rank_of = h->q_rank_of.as<int32_t>(); ps->block_hist = h->q_block_hist.as<int32_t>();
+    ps->counts = h->q_counts.as<int32_t>(); ps->cell_start = h->q_cell_start.as<int32_t>();
+    ps->qx = h->qx.as<float>(); ps->qy = h->qy.as<float>(); ps->qz = h->qz.as<float>(); ps->qperm = h->qperm.as<int32_t>();
+    ps->cert = h->cert.as<float4>(); ps->aux = h->aux.as<int4>();
+    ps->chunk_parts = h->chunk_parts.as<int32_t>(); ps->wave_table = h->wave_table.as<int2>(); ps->n_waves = h->n_waves.as<int32_t>();
 
     h->hctx.qx = h->qx.as<float>(); h->hctx.qy = h->qy.as<float>(); h->hctx.qz = h->qz.as<float>();
     h->hctx.qperm = h->qperm.as<int32_t>();
-    {
-        const int capacity = table_cap;
-        if ((rc = ensure(h, h->chunk_parts, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
-        {   // density wishes: all zero between uses (k_chunk_table_density clears what it consumes)
-            const void* before = h->chunk_factor.p;
-            if ((rc = ensure(h, h->chunk_factor, sizeof(int32_t) * (size_t)(n_chunks + 1)))) return rc;
-            if (h->chunk_factor.p != before) S2M_HIP(h, hipMemsetAsync(h->chunk_factor.p, 0, h->chunk_factor.cap, h->stream));
-        }
-        if ((rc = ensure(h, h->wave_table, sizeof(int2) * (size_t)capacity))) return rc;
-        if ((rc = ensure(h, h->n_waves, 64))) return rc;
-        hipLaunchKernelGGL(k_chunk_parts, dim3((n_chunks + 3) / 4), dim3(256), 0, h->stream, h->qx.as<float>(), h->qy.as<float>(),
-                           h->qz.as<float>(), h->qperm.as<int32_t>(), (int)n, n_chunks, h->base_parts, h->chunk_parts.as<int32_t>());
-        hipLaunchKernelGGL(k_chunk_table, dim3(1), dim3(1024), 0, h->stream, (const int32_t*)h->chunk_parts.as<int32_t>(), (int)n, n_chunks,
-                           capacity, h->wave_table.as<int2>(), h->n_waves.as<int32_t>());
-        S2M_HIP(h, hipGetLastError());
-        h->hctx.wave_table = h->wave_table.as<int2>();
-        h->hctx.n_waves = h->n_waves.as<int32_t>();
-        h->hctx.wave_table_rw = h->wave_table.as<int2>();
-        h->hctx.n_waves_rw = h->n_waves.as<int32_t>();
-        h->hctx.chunk_parts = h->chunk_parts.as<int32_t>();
-        h->hctx.chunk_factor = h->chunk_factor.as<int32_t>();
-        h->hctx.n_chunks = n_chunks;
-        h->hctx.density_pending = 1;
-    }
+    h->hctx.wave_table = h->wave_table.as<int2>();
+    h->hctx.n_waves = h->n_waves.as<int32_t>();
+    h->hctx.wave_table_rw = h->wave_table.as<int2>();
+    h->hctx.n_waves_rw = h->n_waves.as<int32_t>();
+    h->hctx.chunk_parts = h->chunk_parts.as<int32_t>();
+    h->hctx.chunk_factor = h->chunk_factor.as<int32_t>();
+    h->hctx.n_chunks = n_chunks;
+    h->hctx.density_pending = 1;
     h->hctx.npos = h->npos.as<int32_t>();
     h->hctx.cert = h->cert.as<float4>();
     h->hctx.aux = h->aux.as<int4>();
@@ -409,6 +407,37 @@ int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool
     h->hctx.plane_alt = h->plane_alt.as<float4>();
     h->hctx.npos_alt = h->npos_alt.as<int32_t>();
     h->ctx_dirty = true;
+    return S2M_OK;
+}
+
+// the ordering kernels of `nslots` prepared slots (rows with n = 0 do nothing), on `stream`
+void launch_scan_prep(hipStream_t stream, const PrepTable& t, int nslots)
+{
+    int npb = 0, nb = 0, ncb = 0;
+    for (int k = 0; k < nslots; k++) {
+        npb = std::max(npb, (int)t.s[k].npb);
+        nb = std::max(nb, (t.s[k].n + 255) / 256);
+        ncb = std::max(ncb, (t.s[k].n_chunks + 3) / 4);
+    }
+    if (npb == 0) return;
+    hipLaunchKernelGGL(k_polar_count, dim3(npb, nslots), dim3(kPolarBlock), 0, stream, t);
+    hipLaunchKernelGGL(k_polar_prefix, dim3(kPolarCells / 64, nslots), dim3(1024), 0, stream, t);
+    hipLaunchKernelGGL(k_polar_scan, dim3(1, nslots), dim3(1024), 0, stream, t);
+    hipLaunchKernelGGL(k_scatter_scan, dim3(nb, nslots), dim3(256), 0, stream, t);
+    hipLaunchKernelGGL(k_chunk_parts, dim3(ncb, nslots), dim3(256), 0, stream, t);
+    hipLaunchKernelGGL(k_chunk_table, dim3(1, nslots), dim3(1024), 0, stream, t);
+}
+
+int set_scan_impl(s2m_context* h, const void* pts, size_t n, size_t stride, bool on_device)
+{
+    S2M_HIP(h, hipSetDevice(h->device));
+    S2M_HIP(h, hipEventRecord(h->ev_c, h->stream));
+    PrepTable t;
+    int rc = scan_slot_prepare(h, pts, n, stride, on_device, &t.s[0]);
+    if (rc) return rc;
+    if (n == 0) { h->t_set_scan_ms = 0; h->scan_timing_pending = false; return upload_ctx(h); }
+    launch_scan_prep(h->stream, t, 1);
+    S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(h->ev_d, h->stream));
     h->scan_timing_pending = true;
     // (the DevCtx block goes to the device with the next launch that needs it: upload_ctx / push_state)
@@ -454,6 +483,8 @@ int push_state(s2m_context* h, const float pose[6])
 // The plain form  R0 F0 R1 F1 ...  remains for A/B measurements (S2M_NO_FUSE=1).
 // Several scan slots (a batch) advance in lockstep: every launch has one grid row per slot.
 constexpr int kFuseMaxBlocks = 512;
+static_assert(sizeof(CtxTable) <= 4096 && sizeof(StateInitTable) <= 4096 && sizeof(PrepTable) <= 4096 && sizeof(SlotTable) <= 4096,
+              "kernel arguments are limited to 4 KB");
 
 // what one loop launches over: the scan slots (one for a single scan), the widest grid among them, their common workgroup shape
 struct LoopShape {
@@ -474,7 +505,7 @@ LoopShape shape_of(s2m_context* h)
     sh.tbl.st[0] = h->state.as<DevState>();
     sh.nslots = 1; sh.nblocks = h->hctx.nblocks; sh.table_cap = h->hctx.table_cap; sh.wpb = h->hctx.wpb;
     sh.batch = h->parent != nullptr;
-    sh.split = h->split_mode == 1 || (h->split_mode < 0 && (sh.batch || sh.wpb == kBigWaves));
+    sh.split = h->split_mode == 1;
     return sh;
 }
 
@@ -492,6 +523,8 @@ inline void launch_fused(s2m_context* h, const LoopShape& sh, bool hook, int L, 
     if (sh.wpb == kBigWaves) {
         if (hook) launch_k<true, kBigWaves, 4, kFused, kBigWaves>(h->stream, sh, L, fl);
         else      launch_k<false, kBigWaves, 4, kFused, kBigWaves>(h->stream, sh, L, fl);
+    } else if (sh.batch && h->batch_minw == 4 && !hook) {
+        launch_k<false, NW, 4, kFused, NW>(h->stream, sh, L, fl);          // two workgroups per CU (spills in the search path)
     } else {
         if (hook) launch_k<true, NW, 2, kFused, NW>(h->stream, sh, L, fl);
         else      launch_k<false, NW, 2, kFused, NW>(h->stream, sh, L, fl);
@@ -504,6 +537,7 @@ inline void launch_search(s2m_context* h, const LoopShape& sh, int L, bool all)
     constexpr int NW = kBlock / 64;
     const int fl = all ? kFlagAll : 0;
     if (sh.wpb == kBigWaves) launch_k<false, NW, 2, kSearch, kBigWaves>(h->stream, sh, L, fl);
+    else if (sh.batch && h->batch_minw == 4) launch_k<false, NW, 4, kSearch, NW>(h->stream, sh, L, fl);
     else                     launch_k<false, NW, 2, kSearch, NW>(h->stream, sh, L, fl);
 }
 
@@ -547,7 +581,7 @@ void enqueue_loop(s2m_context* h, const LoopShape& sh, hipEvent_t* events, bool 
 {
     const int n = h->prm.max_iter;
     if (L1 < 0) L1 = n;
-    const bool fuse = h->fuse_solve && sh.nblocks <= h->fuse_max_blocks;
+    const bool fuse = h->fuse_solve && sh.nblocks * sh.nslots <= h->fuse_max_blocks;     // the whole grid co-resident (see above)
     if (h->density_raw > 0 && L0 == 0) launch_density(h, sh);
     for (int L = L0; L < L1; L++) {
         const int slot = !coarse ? 2 * L : (L == 0 ? 0 : (L == 1 ? 2 : (L == n - 1 ? 6 : 4)));
@@ -751,6 +785,8 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_SEGMENT")) h->seg_iters = atoi(e);
     if (const char* e = getenv("S2M_SPLIT")) h->split_mode = atoi(e);
     if (const char* e = getenv("S2M_LOCKSTEP")) h->lockstep = !(e[0] == '0');
+    if (const char* e = getenv("S2M_BATCH_MINW")) h->batch_minw = atoi(e);
+    if (const char* e = getenv("S2M_BATCH_ENTRIES")) h->batch_entries = atoi(e);
     h->fuse_max_blocks = kFuseMaxBlocks;
     if (const char* e = getenv("S2M_FUSE_MAX")) h->fuse_max_blocks = atoi(e);
 
@@ -800,10 +836,15 @@ int s2m_destroy(s2m_handle h)
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (s2m_context* k : h->kids) (void)s2m_destroy(k);
     h->kids.clear();
+    if (h->kid_states.p) (void)hipFree(h->kid_states.p);
+    if (h->h_kid_states) (void)hipHostFree(h->h_kid_states);
+    if (h->state_borrowed) { h->state.p = nullptr; h->h_state = nullptr; }
     for (auto& kv : h->batch_graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipStream_t st : h->branch_streams) (void)hipStreamDestroy(st);
     for (hipEvent_t e : h->branch_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->prep_events) (void)hipEventDestroy(e);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_prep) (void)hipEventDestroy(h->ev_prep);
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
@@ -904,7 +945,8 @@ int s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu, s
     if (!r.skipped) {
         S2M_HIP(h, hipSetDevice(h->device));
         S2M_HIP(h, hipStreamSynchronize(h->stream));
-        S2M_HIP(h, hipEventElapsedTime(&h->t_optimize_ms, h->ev_a, h->ev_b));
+        if (h->parent) h->t_optimize_ms = h->parent->t_optimize_ms;      // a slot of a batch: the batch was timed as a whole
+        else S2M_HIP(h, hipEventElapsedTime(&h->t_optimize_ms, h->ev_a, h->ev_b));
         if (h->seg_pending && !h->h_state[1].done) {
             // the first range did not converge: the rest of the loop
             int rc2 = launch_loop(h, 2);
@@ -998,15 +1040,39 @@ int ensure_kids(s2m_context* h, int n)
         if (rc) return fail(h, rc, "batch: could not create a scan slot");
         k->parent = h;
         k->hctx.ablate = h->hctx.ablate;
+        {   // the slot's loop state and trace live in the parent's block
+            constexpr size_t kStride = sizeof(DevState) + sizeof(s2m_iter_trace) * kMaxIter;
+            if (!h->kid_states.p) {
+                if (ensure(h, h->kid_states, kStride * kMaxSlots) != S2M_OK ||
+                    hipHostMalloc((void**)&h->h_kid_states, sizeof(DevState) + kStride * kMaxSlots) != hipSuccess) {
+                    (void)s2m_destroy(k);
+                    return fail(h, S2M_ERR_HIP, "batch: state block allocation failed");
+                }
+            }
+            const size_t slot = h->kids.size();
+            (void)hipFree(k->state.p);
+            (void)hipHostFree(k->h_state);
+            k->state.p = h->kid_states.as<unsigned char>() + kStride * slot; k->state.cap = kStride;
+            k->h_state = reinterpret_cast<DevState*>(h->h_kid_states + kStride * slot);      // [1] = the download area of this slot
+            k->h_trace = reinterpret_cast<s2m_iter_trace*>(k->h_state + 2);
+            k->state_borrowed = true;
+            k->hctx.state = k->state.as<DevState>();
+            k->hctx.trace = reinterpret_cast<s2m_iter_trace*>(k->state.as<DevState>() + 1);
+            k->ctx_dirty = true;
+        }
         h->kids.push_back(k);
         hipStream_t st = nullptr;
-        hipEvent_t ev = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+        hipEvent_t ev = nullptr, ev2 = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess)
             return fail(h, S2M_ERR_HIP, "batch: stream / event creation failed");
         h->branch_streams.push_back(st);
         h->branch_events.push_back(ev);
+        h->prep_events.push_back(ev2);
+        h->prep_pending.push_back(0);
     }
     if (!h->ev_fork && hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess) return fail(h, S2M_ERR_HIP, "batch: event creation failed");
+    if (!h->ev_prep && hipEventCreateWithFlags(&h->ev_prep, hipEventDisableTiming) != hipSuccess) return fail(h, S2M_ERR_HIP, "batch: event creation failed");
     return S2M_OK;
 }
 
@@ -1037,7 +1103,7 @@ int get_batch_graph(s2m_context* h, const std::vector<int>& live, hipGraphExec_t
                 sh.nblocks = std::max(sh.nblocks, k->hctx.nblocks);
                 sh.table_cap = std::max(sh.table_cap, k->hctx.table_cap);
             }
-            sh.split = h->split_mode != 0;
+            sh.split = h->split_mode == 1;
             if (sh.nslots) loops.push_back(sh);
         }
     } else
@@ -1074,7 +1140,39 @@ int s2m_batch_set_scan(s2m_handle h, int slot, const void* pts, size_t n, size_t
     if (rc) return rc;
     s2m_context* k = h->kids[(size_t)slot];
     if ((rc = adopt_map(h, k))) return fail(h, rc, k->err.c_str());
-    if ((rc = set_scan_impl(k, pts, n, stride_bytes, on_device != 0))) return fail(h, rc, k->err.c_str());
+    // The ordering of one slot's scan does not depend on the others': it runs on the slot's own stream, behind everything
+    // issued on the handle's stream so far (the previous batch read the slot's buffers), and the batch launch waits for it.
+    hipStream_t br = h->branch_streams[(size_t)slot];
+    S2M_HIP(h, hipEventRecord(h->ev_prep, h->stream));
+    S2M_HIP(h, hipStreamWaitEvent(br, h->ev_prep, 0));
+    k->stream = br;
+    rc = set_scan_impl(k, pts, n, stride_bytes, on_device != 0);
+    k->stream = h->stream;
+    if (rc) { (void)hipStreamSynchronize(br); return fail(h, rc, k->err.c_str()); }
+    S2M_HIP(h, hipEventRecord(h->prep_events[(size_t)slot], br));
+    h->prep_pending[(size_t)slot] = 1;
+    return S2M_OK;
+}
+
+int s2m_batch_set_scans(s2m_handle h, int n_scans, const void* const* scans, const size_t* sizes, size_t stride_bytes, int on_device)
+{
+    if (!h || n_scans < 1 || n_scans > kMaxSlots || !scans || !sizes) return S2M_ERR_INVALID_ARG;
+    S2M_HIP(h, hipSetDevice(h->device));
+    int rc = ensure_kids(h, n_scans);
+    if (rc) return rc;
+    for (int b0 = 0; b0 < n_scans; b0 += kPrepSlots) {
+        PrepTable t;
+        const int nb = std::min(kPrepSlots, n_scans - b0);
+        for (int j = 0; j < nb; j++) {
+            s2m_context* k = h->kids[(size_t)(b0 + j)];
+            if ((rc = adopt_map(h, k))) return fail(h, rc, k->err.c_str());
+            if ((rc = scan_slot_prepare(k, scans[b0 + j], sizes[b0 + j], stride_bytes, on_device != 0, &t.s[j]))) return fail(h, rc, k->err.c_str());
+            k->t_set_scan_ms = 0; k->scan_timing_pending = false;
+        }
+        launch_scan_prep(h->stream, t, nb);
+        S2M_HIP(h, hipGetLastError());
+    }
+    if (!on_device) S2M_HIP(h, hipStreamSynchronize(h->stream));       // the callers' buffers are free again
     return S2M_OK;
 }
 
@@ -1085,6 +1183,8 @@ int s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses)
     S2M_HIP(h, hipSetDevice(h->device));
     std::vector<int> live;
     int rc;
+    for (size_t b = 0; b < h->prep_pending.size(); b++)
+        if (h->prep_pending[b]) { S2M_HIP(h, hipStreamWaitEvent(h->stream, h->prep_events[b], 0)); h->prep_pending[b] = 0; }
     for (int b = 0; b < n_scans; b++) {
         s2m_context* k = h->kids[(size_t)b];
         if (!k->have_scan) return fail(h, S2M_ERR_NO_SCAN, "s2m_batch_set_scan has not been called for every slot");
@@ -1099,9 +1199,33 @@ int s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses)
         k->pending_skipped = 0;
         if (k->n_m == 0) { k->pending_skipped = 1; continue; }                            // :1297
         if ((int)k->n_q <= k->prm.min_feats) { k->pending_skipped = 2; continue; }         // :1300
-        if ((rc = upload_ctx(k))) return fail(h, rc, k->err.c_str());
-        if ((rc = push_state(k, poses + 6 * (size_t)b))) return fail(h, rc, k->err.c_str());
         live.push_back(b);
+    }
+    {   // DevCtx blocks that changed and the loop state every live slot starts from: one launch per kCtxSlots / kInitSlots slots
+        CtxTable ct; int nc = 0;
+        auto flush_ctx = [&]() { if (nc) { for (int j = nc; j < kCtxSlots; j++) ct.dst[j] = nullptr; hipLaunchKernelGGL(k_set_ctxs, dim3(nc), dim3(64), 0, h->stream, ct); nc = 0; } };
+        for (int b = 0; b < n_scans; b++) {
+            s2m_context* k = h->kids[(size_t)b];
+            if (!k->ctx_dirty) continue;
+            ct.dst[nc] = k->dctx.as<DevCtx>(); ct.v[nc] = k->hctx; nc++;
+            k->ctx_dirty = false;
+            if (nc == kCtxSlots) flush_ctx();
+        }
+        flush_ctx();
+        StateInitTable it; int ni = 0;
+        auto flush_init = [&]() { if (ni) { for (int j = ni; j < kInitSlots; j++) it.s[j].dst = nullptr; hipLaunchKernelGGL(k_init_states, dim3(ni), dim3(256), 0, h->stream, it); ni = 0; } };
+        for (int b : live) {
+            s2m_context* k = h->kids[(size_t)b];
+            DevState s0;
+            fill_state(k, &s0, poses + 6 * (size_t)b);
+            StateInit& si = it.s[ni++];
+            si.dst = k->state.as<DevState>(); si.n_waves = k->n_waves.as<int32_t>();
+            memcpy(si.pose, s0.pose, sizeof(si.pose)); memcpy(si.T, s0.T, sizeof(si.T)); memcpy(si.sc, s0.sc, sizeof(si.sc));
+            memcpy(si.matP, s0.matP, sizeof(si.matP)); si.isDegenerate = s0.isDegenerate;
+            if (ni == kInitSlots) flush_init();
+        }
+        flush_init();
+        S2M_HIP(h, hipGetLastError());
     }
     S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
     if (!live.empty()) {
@@ -1110,11 +1234,12 @@ int s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses)
         S2M_HIP(h, hipGraphLaunch(exec, h->stream));
     }
     S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
-    for (int b : live) {
-        s2m_context* k = h->kids[(size_t)b];
-        k->hctx.density_pending = 0;
-        S2M_HIP(h, hipEventRecord(k->ev_a, h->stream)); S2M_HIP(h, hipEventRecord(k->ev_b, h->stream));     // (collect reads a per-handle time)
-        S2M_HIP(h, hipMemcpyAsync(&k->h_state[1], k->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * k->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
+    for (int b : live) h->kids[(size_t)b]->hctx.density_pending = 0;
+    if (!live.empty()) {
+        // state + trace of every slot up to the last live one, in one copy (the slots' blocks are contiguous)
+        constexpr size_t kStride = sizeof(DevState) + sizeof(s2m_iter_trace) * kMaxIter;
+        const size_t upto = (size_t)live.back() + 1;
+        S2M_HIP(h, hipMemcpyAsync(h->h_kid_states + sizeof(DevState), h->kid_states.p, kStride * upto, hipMemcpyDeviceToHost, h->stream));
     }
     return S2M_OK;
 }
@@ -1137,11 +1262,9 @@ int s2m_optimize_batch(s2m_handle h, int n_scans, const void* const* scans, cons
                        float* poses, const s2m_imu_init* imu, s2m_result* out)
 {
     if (!h || n_scans < 1 || n_scans > 64 || !scans || !sizes || !poses) return S2M_ERR_INVALID_ARG;
-    for (int b = 0; b < n_scans; b++) {
-        const int rc = s2m_batch_set_scan(h, b, scans[b], sizes[b], stride_bytes, 0);
-        if (rc) return rc;
-    }
-    const int rc = s2m_optimize_batch_launch(h, n_scans, poses);
+    int rc = s2m_batch_set_scans(h, n_scans, scans, sizes, stride_bytes, 0);
+    if (rc) return rc;
+    rc = s2m_optimize_batch_launch(h, n_scans, poses);
     if (rc) return rc;
     return s2m_optimize_batch_collect(h, n_scans, poses, imu, out);
 }

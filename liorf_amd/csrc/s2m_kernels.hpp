@@ -261,10 +261,12 @@ __device__ __forceinline__ int polar_cell(float x, float y)
 // (Device-scope returning atomics, the obvious alternative, are also served memory-side on this multi-die part: 120 k
 // of them cost 27 us.)
 constexpr int kPolarBlock = 1024;
-__global__ __launch_bounds__(kPolarBlock) void k_polar_count(const unsigned char* __restrict__ pts, size_t stride, int n,
-                                                             int32_t* __restrict__ cell_of, int32_t* __restrict__ rank_of,
-                                                             int32_t* __restrict__ block_hist)
+__global__ __launch_bounds__(kPolarBlock) void k_polar_count(const PrepTable tbl)
 {
+    const PrepSlot& ps = tbl.s[blockIdx.y];
+    if ((int)blockIdx.x >= ps.npb) return;
+    const unsigned char* __restrict__ pts = ps.pts; const size_t stride = ps.stride; const int n = ps.n;
+    int32_t* __restrict__ cell_of = ps.cell_of; int32_t* __restrict__ rank_of = ps.rank_of; int32_t* __restrict__ block_hist = ps.block_hist;
     __shared__ int32_t hist[kPolarCells];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     for (int k = t; k < kPolarCells; k += kPolarBlock) hist[k] = 0;
@@ -298,8 +300,10 @@ __global__ __launch_bounds__(kPolarBlock) void k_polar_count(const unsigned char
 
 // Column-wise exclusive prefix of the workgroup histograms over the workgroups, in place, and the cell totals.
 // 64 columns x 16 segments of workgroups per 1024 threads: consecutive lanes read consecutive columns.
-__global__ __launch_bounds__(1024) void k_polar_prefix(int32_t* __restrict__ H, int nb, int32_t* __restrict__ counts)
+__global__ __launch_bounds__(1024) void k_polar_prefix(const PrepTable tbl)
 {
+    const PrepSlot& ps = tbl.s[blockIdx.y];
+    int32_t* __restrict__ H = ps.block_hist; const int nb = ps.npb; int32_t* __restrict__ counts = ps.counts;
     __shared__ int32_t seg[16][64];
     const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
@@ -322,8 +326,10 @@ __global__ __launch_bounds__(1024) void k_polar_prefix(int32_t* __restrict__ H, 
 
 // exclusive scan of the 16384 polar cell counts by one workgroup (16 per thread); the counts are
 // zeroed as they are read, ready for the next scan
-__global__ __launch_bounds__(1024) void k_polar_scan(int32_t* __restrict__ counts, int32_t* __restrict__ start)
+__global__ __launch_bounds__(1024) void k_polar_scan(const PrepTable tbl)
 {
+    const PrepSlot& ps = tbl.s[blockIdx.y];
+    int32_t* __restrict__ counts = ps.counts; int32_t* __restrict__ start = ps.cell_start;
     __shared__ int32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     int32_t v[16];
@@ -452,12 +458,14 @@ __global__ void k_scatter_map(const unsigned char* __restrict__ pts, size_t stri
     map_sorted[pos] = make_float4(p[0], p[1], p[2], __int_as_float(i));
 }
 
-__global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t stride, int n,
-                               const int32_t* __restrict__ cell_of, const int32_t* __restrict__ rank_of,
-                               const int32_t* __restrict__ cell_start, const int32_t* __restrict__ block_hist,
-                               float* __restrict__ qx, float* __restrict__ qy, float* __restrict__ qz,
-                               int32_t* __restrict__ qperm, float4* __restrict__ cert, int4* __restrict__ aux)
+__global__ void k_scatter_scan(const PrepTable tbl)
 {
+    const PrepSlot& ps = tbl.s[blockIdx.y];
+    const unsigned char* __restrict__ pts = ps.pts; const size_t stride = ps.stride; const int n = ps.n;
+    const int32_t* __restrict__ cell_of = ps.cell_of; const int32_t* __restrict__ rank_of = ps.rank_of;
+    const int32_t* __restrict__ cell_start = ps.cell_start; const int32_t* __restrict__ block_hist = ps.block_hist;
+    float* __restrict__ qx = ps.qx; float* __restrict__ qy = ps.qy; float* __restrict__ qz = ps.qz;
+    int32_t* __restrict__ qperm = ps.qperm; float4* __restrict__ cert = ps.cert; int4* __restrict__ aux = ps.aux;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
@@ -475,10 +483,11 @@ __global__ void k_scatter_scan(const unsigned char* __restrict__ pts, size_t str
 // stage and sweep a large map tile, and the slowest wave sets the kernel time.  Such chunks are
 // given to 2, 4 or 8 waves (32 / 16 / 8 points each: tighter boxes, run in parallel).  The extent is
 // measured in the lidar frame - a rigid transform does not change it.
-__global__ __launch_bounds__(256) void k_chunk_parts(float* __restrict__ qx, float* __restrict__ qy,
-                                                     float* __restrict__ qz, int32_t* __restrict__ qperm, int n, int n_chunks,
-                                                     int base_parts, int32_t* __restrict__ parts)
+__global__ __launch_bounds__(256) void k_chunk_parts(const PrepTable tbl)
 {
+    const PrepSlot& ps = tbl.s[blockIdx.y];
+    float* __restrict__ qx = ps.qx; float* __restrict__ qy = ps.qy; float* __restrict__ qz = ps.qz; int32_t* __restrict__ qperm = ps.qperm;
+    const int n = ps.n, n_chunks = ps.n_chunks, base_parts = ps.base_parts; int32_t* __restrict__ parts = ps.chunk_parts;
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= n_chunks) return;
@@ -620,10 +629,10 @@ __device__ __forceinline__ void chunk_table_body(const int32_t* __restrict__ par
 }
 
 // per s2m_set_scan: extent-based parts only
-__global__ __launch_bounds__(1024) void k_chunk_table(const int32_t* __restrict__ parts, int n, int n_chunks, int capacity,
-                                                      int2* __restrict__ table, int32_t* __restrict__ n_waves_out)
+__global__ __launch_bounds__(1024) void k_chunk_table(const PrepTable tbl)
 {
-    chunk_table_body(parts, n, n_chunks, capacity, table, n_waves_out, nullptr, nullptr);
+    const PrepSlot& ps = tbl.s[blockIdx.y];
+    chunk_table_body(ps.chunk_parts, ps.n, ps.n_chunks, ps.capacity, ps.wave_table, ps.n_waves, nullptr, nullptr);
 }
 
 // per scan before launch 0, inside the captured loop: everything comes from the DevCtx block
@@ -1377,6 +1386,26 @@ __global__ void k_set_ctx(DevCtx* dst, DevCtx v) { if (threadIdx.x == 0 && block
 __global__ void k_set_ctx_state(DevCtx* cdst, DevCtx c, DevState* dst, DevState v, const int32_t* n_waves)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) { *cdst = c; v.n_waves = n_waves ? *n_waves : 0; *dst = v; }
+}
+
+// the same for the scan slots of a batch: one launch for all of them (blockIdx.x = slot)
+__global__ void k_set_ctxs(const CtxTable t) { if (threadIdx.x == 0 && t.dst[blockIdx.x]) *t.dst[blockIdx.x] = t.v[blockIdx.x]; }
+__global__ __launch_bounds__(256) void k_init_states(const StateInitTable t)
+{
+    const StateInit& si = t.s[blockIdx.x];
+    if (!si.dst) return;
+    float* w = reinterpret_cast<float*>(si.dst);
+    for (int k = threadIdx.x; k < (int)(sizeof(DevState) / 4); k += blockDim.x) w[k] = 0.0f;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DevState* d = si.dst;
+        for (int k = 0; k < 6; k++) { d->pose[k] = si.pose[k]; d->pose2[0][k] = si.pose[k]; d->sc[k] = si.sc[k]; }
+        for (int k = 0; k < 12; k++) d->T[k] = si.T[k];
+        for (int k = 0; k < 36; k++) d->matP[k] = si.matP[k];
+        d->isDegenerate = si.isDegenerate;
+        d->T_valid = 1;
+        d->n_waves = si.n_waves ? *si.n_waves : 0;
+    }
 }
 
 __global__ void k_set_state(DevState* dst, DevState v, const int32_t* n_waves)

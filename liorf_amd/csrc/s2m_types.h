@@ -106,4 +106,27 @@ struct SlotTable {
     DevState*     st[kMaxSlots];
 };
 
+// Scan preparation (ordering + wave table) of up to kPrepSlots scans per launch, blockIdx.y = slot: everything a slot's six
+// small kernels need, by value, so that a batch of scans costs six launches and not six per scan.
+struct PrepSlot {
+    const unsigned char* pts; size_t stride;
+    int32_t n, n_chunks, base_parts, capacity, npb;
+    int32_t *cell_of, *rank_of, *block_hist, *counts, *cell_start;
+    float *qx, *qy, *qz; int32_t* qperm; float4* cert; int4* aux;
+    int32_t* chunk_parts; int2* wave_table; int32_t* n_waves;
+};
+constexpr int kPrepSlots = 16;
+struct PrepTable { PrepSlot s[kPrepSlots]; };
+
+// The loop state a scan starts from, for up to kInitSlots slots per launch (k_init_states): what fill_state sets, the rest is zero.
+struct StateInit {
+    DevState* dst; const int32_t* n_waves;
+    float pose[6], T[12], sc[6], matP[36];
+    int32_t isDegenerate;
+};
+constexpr int kInitSlots = 12;
+struct StateInitTable { StateInit s[kInitSlots]; };
+constexpr int kCtxSlots = 8;
+struct CtxTable { DevCtx* dst[kCtxSlots]; DevCtx v[kCtxSlots]; };
+
 }  // namespace s2m

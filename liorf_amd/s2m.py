@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "s2m_version", "s2m_default_params", "s2m_create", "s2m_destroy", "s2m_last_error", "s2m_set_params", "s2m_get_params",
     "s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device",
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
-    "s2m_optimize_batch", "s2m_batch_set_scan", "s2m_optimize_batch_launch", "s2m_optimize_batch_collect", "s2m_batch_get_trace",
+    "s2m_optimize_batch", "s2m_batch_set_scan", "s2m_batch_set_scans", "s2m_optimize_batch_launch", "s2m_optimize_batch_collect", "s2m_batch_get_trace",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
     "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile", "s2m_debug_time_steady", "s2m_time_loop_launches",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
@@ -133,6 +133,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
     L.s2m_optimize_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, fp, C.POINTER(ImuInit), C.POINTER(Result)]
     L.s2m_batch_set_scan.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.s2m_batch_set_scans.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int]
     L.s2m_optimize_batch_launch.argtypes = [vp, C.c_int, fp]
     L.s2m_optimize_batch_collect.argtypes = [vp, C.c_int, fp, C.POINTER(ImuInit), C.POINTER(Result)]
     L.s2m_batch_get_trace.argtypes = [vp, C.c_int, C.POINTER(IterTrace), C.c_int]
@@ -390,6 +391,24 @@ class MapOptimizationS2M:
         else:
             a, n, st = _records(scan)
             self._check(self.lib.s2m_batch_set_scan(self.h, slot, a.ctypes.data, n, st, 0), "s2m_batch_set_scan")
+
+    def batchSetScans(self, scans=None, device_ptrs=None):
+        """Install slots 0 .. n-1 at once (s2m_batch_set_scans): host records, or device_ptrs=[(ptr, n, stride_bytes), ...]."""
+        if device_ptrs is not None:
+            n = len(device_ptrs)
+            st = device_ptrs[0][2]
+            ptrs = (C.c_void_p * n)(*[C.c_void_p(d[0]) for d in device_ptrs])
+            sizes = (C.c_size_t * n)(*[d[1] for d in device_ptrs])
+            self._check(self.lib.s2m_batch_set_scans(self.h, n, ptrs, sizes, st, 1), "s2m_batch_set_scans")
+        else:
+            keep = [_records(sc) for sc in scans]
+            n = len(keep)
+            st = keep[0][2]
+            if any(k[2] != st for k in keep):
+                raise ValueError("all scans of a batch must share one record stride")
+            ptrs = (C.c_void_p * n)(*[C.c_void_p(k[0].ctypes.data) for k in keep])
+            sizes = (C.c_size_t * n)(*[k[1] for k in keep])
+            self._check(self.lib.s2m_batch_set_scans(self.h, n, ptrs, sizes, st, 0), "s2m_batch_set_scans")
 
     def batchLaunch(self, poses):
         p = np.ascontiguousarray(poses, np.float32).reshape(-1, 6)

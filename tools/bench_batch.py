@@ -9,6 +9,8 @@ from liorf_amd import s2m, synth
 
 name = sys.argv[1] if len(sys.argv) > 1 else "kitti64"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+BS = tuple(int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1, 2, 4, 8)
+EARLY = tuple(int(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else (0, 1)
 dev = torch.device("cuda", 0)
 cfgs = [synth.make_config(name, scan_index=k) for k in range(8)]
 n_m = cfgs[0]["map"].shape[0]
@@ -16,13 +18,12 @@ d_map = torch.from_numpy(synth.to_xyzi(cfgs[0]["map"])).to(dev)
 d_scans = [torch.from_numpy(synth.to_xyzi(c["scan"])).to(dev) for c in cfgs]
 poses = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
 out = {"workload": name, "n_m": n_m, "n_q": int(d_scans[0].shape[0]), "steps": steps, "batches": []}
-for early in (0, 1):
+for early in EARLY:
     eng = s2m.MapOptimizationS2M(early_exit=early)
     eng.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
-    for B in (1, 2, 4, 8):
+    for B in BS:
         def step():
-            for b in range(B):
-                eng.batchSetScan(b, device_ptr=(d_scans[b].data_ptr(), int(d_scans[b].shape[0]), 32))
+            eng.batchSetScans(device_ptrs=[(d_scans[b].data_ptr(), int(d_scans[b].shape[0]), 32) for b in range(B)])
             eng.batchLaunch(poses[:B])
             return eng.batchCollect()
         for _ in range(3):
