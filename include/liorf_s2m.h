@@ -196,6 +196,9 @@ int  s2m_debug_device_trig(s2m_handle h, const float* x, size_t n, float* s, flo
 /* Raw device time (ms) of the last s2m_optimize* call, measured with HIP events
  * on the handle's stream; and of the last s2m_set_map / s2m_set_scan index build. */
 int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float* set_scan_ms);
+/* Diagnostics: workgroups the certify kernels of the last collected loop handed to the search kernel (slot < 0: the handle's own
+ * loop; slot >= 0: that scan slot of the last batch). */
+int  s2m_debug_deferred(s2m_handle h, int slot);
 /* Benchmark helper: runs `reps` complete LM loops (max_iter iterations, early exit as
  * configured, each loop starting like a fresh scan) on the resident scan + map with plain
  * launches and a HIP-event pair on the handle's stream around every launch of the

@@ -106,6 +106,8 @@ struct s2m_context {
     hipEvent_t ev_a2 = nullptr, ev_b2 = nullptr;
     int  split_mode = -1;              // env S2M_SPLIT: 1 = every loop runs certify + search kernels, 0 = every loop the fused kernel, default: split for the
                                        // scan slots of a batch and for 16-wave workgroups (large scans), fused for a single small scan
+    int  lean_epw = 2;                 // env S2M_LEAN_EPW=1: one entry per wave in the lean certify kernel (A/B measurements)
+    bool lean_certify = true;          // env S2M_LEAN=0: the certify role by the general kernel even where the 64-register one applies
     int  batch_entries = 1;            // env S2M_BATCH_ENTRIES: wave-table entries per wave in the scan slots of a batch (fewer, longer-running workgroups)
     int  batch_minw = 4;               // env S2M_BATCH_MINW=4: the search / fused kernel of batch slots in the 128-register build
     bool lockstep = true;              // env S2M_LOCKSTEP=0: the scans of a batch as parallel branches of the graph instead of one grid row each (A/B measurements)
@@ -495,6 +497,7 @@ struct LoopShape {
     int wpb = kBlock / 64;  // waves per workgroup (DevCtx::wpb, the same for every slot)
     bool batch = false;     // scan slots of a batch
     bool split = false;     // C + S per iteration instead of R
+    bool split_auto = false; // split if the loop's iterations are closed by k_finalize and the lean certify kernel applies
 };
 
 LoopShape shape_of(s2m_context* h)
@@ -541,20 +544,25 @@ inline void launch_search(s2m_context* h, const LoopShape& sh, int L, bool all)
     else                     launch_k<false, NW, 2, kSearch, NW>(h->stream, sh, L, fl);
 }
 
-inline void launch_certify(s2m_context* h, const LoopShape& sh, int L, int solve_prev)
+inline void launch_certify(s2m_context* h, const LoopShape& sh, int L, int solve_prev, bool fused_loop)
 {
     constexpr int NW = kBlock / 64;
     const int fl = solve_prev ? kFlagSolvePrev : 0;
-    if (sh.wpb == kBigWaves) launch_k<false, kBigWaves, kCertifyWavesBig, kCertify, kBigWaves>(h->stream, sh, L, fl);
+    if (!fused_loop && sh.wpb == NW && h->lean_certify)      // iterations closed by k_finalize: the 64-register kernel
+    {
+        if (h->lean_epw == 1) hipLaunchKernelGGL((k_certify_lean<NW, 1, kCertifyLeanWaves>), dim3(sh.nblocks, sh.nslots), dim3(NW * 64), 0, h->stream, sh.tbl, L);
+        else hipLaunchKernelGGL((k_certify_lean<NW, kCertifyLeanEpw, kCertifyLeanWaves>), dim3(sh.nblocks, sh.nslots), dim3(NW / kCertifyLeanEpw * 64), 0, h->stream, sh.tbl, L);
+    }
+    else if (sh.wpb == kBigWaves) launch_k<false, kBigWaves, kCertifyWavesBig, kCertify, kBigWaves>(h->stream, sh, L, fl);
     else                     launch_k<false, NW, kCertifyWaves, kCertify, NW>(h->stream, sh, L, fl);
 }
 
 // iteration L of the loop: R(L), or C(L) S(L)
-inline void launch_iteration(s2m_context* h, const LoopShape& sh, int L, int solve_prev)
+inline void launch_iteration(s2m_context* h, const LoopShape& sh, int L, int solve_prev, bool fused_loop = true)
 {
     if (!sh.split) { launch_fused(h, sh, false, L, solve_prev); return; }
     if (L == 0) { launch_search(h, sh, 0, true); return; }
-    launch_certify(h, sh, L, solve_prev);
+    launch_certify(h, sh, L, solve_prev, fused_loop);
     launch_search(h, sh, L, false);
 }
 
@@ -577,17 +585,19 @@ inline void launch_density(s2m_context* h, const LoopShape& sh)
 // `events`, if given, holds 2*n events recorded around every iteration's launches; with `coarse` only four pairs are recorded - around
 // launch 0, launch 1, the run of back-to-back launches 2 .. n-2 (slots 4, 5) and launch n-1 (slots 6, 7) - so that the event
 // packets do not break up the loop's back-to-back dispatch.
-void enqueue_loop(s2m_context* h, const LoopShape& sh, hipEvent_t* events, bool coarse = false, int L0 = 0, int L1 = -1)
+void enqueue_loop(s2m_context* h, const LoopShape& sh_in, hipEvent_t* events, bool coarse = false, int L0 = 0, int L1 = -1)
 {
     const int n = h->prm.max_iter;
     if (L1 < 0) L1 = n;
-    const bool fuse = h->fuse_solve && sh.nblocks * sh.nslots <= h->fuse_max_blocks;     // the whole grid co-resident (see above)
+    const bool fuse = h->fuse_solve && sh_in.nblocks * sh_in.nslots <= h->fuse_max_blocks;     // the whole grid co-resident (see above)
+    LoopShape sh = sh_in;
+    if (sh.split_auto && !fuse && sh.wpb == kBlock / 64 && h->lean_certify) sh.split = true;
     if (h->density_raw > 0 && L0 == 0) launch_density(h, sh);
     for (int L = L0; L < L1; L++) {
         const int slot = !coarse ? 2 * L : (L == 0 ? 0 : (L == 1 ? 2 : (L == n - 1 ? 6 : 4)));
         const bool open = events && (!coarse || L <= 2 || L == n - 1), close = events && (!coarse || L <= 1 || L >= n - 2);
         if (open) (void)hipEventRecord(events[slot], h->stream);
-        launch_iteration(h, sh, L, (fuse && L >= 2 && L != L0) ? 1 : 0);
+        launch_iteration(h, sh, L, (fuse && L >= 2 && L != L0) ? 1 : 0, fuse);
         if (close) (void)hipEventRecord(events[slot + 1], h->stream);
         if (!fuse || L == 0 || L == L1 - 1) launch_finalize(h, sh, L, 0);
     }
@@ -787,6 +797,8 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_LOCKSTEP")) h->lockstep = !(e[0] == '0');
     if (const char* e = getenv("S2M_BATCH_MINW")) h->batch_minw = atoi(e);
     if (const char* e = getenv("S2M_BATCH_ENTRIES")) h->batch_entries = atoi(e);
+    if (const char* e = getenv("S2M_LEAN")) h->lean_certify = !(e[0] == '0');
+    if (const char* e = getenv("S2M_LEAN_EPW")) h->lean_epw = atoi(e);
     h->fuse_max_blocks = kFuseMaxBlocks;
     if (const char* e = getenv("S2M_FUSE_MAX")) h->fuse_max_blocks = atoi(e);
 
@@ -1103,7 +1115,8 @@ int get_batch_graph(s2m_context* h, const std::vector<int>& live, hipGraphExec_t
                 sh.nblocks = std::max(sh.nblocks, k->hctx.nblocks);
                 sh.table_cap = std::max(sh.table_cap, k->hctx.table_cap);
             }
-            sh.split = h->split_mode == 1;
+            sh.split = h->split_mode == 1;         // (default: decided in enqueue_loop - split where the loop is not fused)
+            sh.split_auto = h->split_mode == 2;    // (S2M_SPLIT=2: certify + search where the loop is not fused; measured no faster than the fused kernel in lockstep)
             if (sh.nslots) loops.push_back(sh);
         }
     } else
@@ -1403,6 +1416,15 @@ int s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6]
     if (AtB) memcpy(AtB, h->h_state[1].AtB, sizeof(float) * 6);
     if (n_sel) *n_sel = h->h_state[1].n_sel_last;
     return S2M_OK;
+}
+
+// Diagnostics: workgroups the certify kernels of the last collected loop handed to the search kernel (0 for a fused loop;
+// slot >= 0: that scan slot of the last batch).
+int s2m_debug_deferred(s2m_handle h, int slot)
+{
+    if (!h) return S2M_ERR_INVALID_ARG;
+    if (slot >= 0) { if (slot >= (int)h->kids.size()) return S2M_ERR_INVALID_ARG; h = h->kids[(size_t)slot]; }
+    return h->h_state ? h->h_state[1].deferred_total : 0;
 }
 
 int s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float* set_scan_ms)

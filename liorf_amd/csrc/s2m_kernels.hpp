@@ -1292,6 +1292,23 @@ __device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp
     return s_out[6] != 0.0f;
 }
 
+// transPointAssociateToMap (:1069-1072) and the LM trig (:1170-1175) from a pose: lanes 0..2 of the calling wave take one
+// angle each (glibc's sinf / cosf arithmetic, see glibc_sincosf: what the host's libm would return); result in every lane.
+__device__ __forceinline__ void build_transform(const float (&pose)[6], int lane, float (&T)[12], float (&sc6)[6])
+{
+    const float ang = (lane == 0) ? pose[2] : ((lane == 1) ? pose[1] : pose[0]);   // lane 0: yaw, 1: pitch, 2+: roll
+    float snf, csf;
+    glibc_sincosf_both(ang, snf, csf);
+    const float B = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 0)), A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 0));
+    const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 1)), C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 1));
+    const float F = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 2)), E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 2));
+    const float DE = D * E, DF = D * F;
+    T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = pose[3];
+    T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = pose[4];
+    T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = pose[5];
+    sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
+}
+
 // ------------------------------------------------------------------------------------------
 // Density-aware re-split of the wave table, once per scan before launch 0.  k_chunk_parts can only
 // look at the extent of a chunk in the lidar frame; how many map points fall into a wave's box is
@@ -1367,7 +1384,20 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const SlotTable tbl, i
     __shared__ LmShared sh;
     __shared__ float s_out[8];
     float pose[6];
-    lm_close_iteration<kFinThreads, true>(cp, st, nb_act, iter, true, mode == 1, pose0, degen0, sh, s_out, pose);
+    const bool ended = lm_close_iteration<kFinThreads, true>(cp, st, nb_act, iter, true, mode == 1, pose0, degen0, sh, s_out, pose);
+    // the transform of the new pose, once, for every workgroup of the next registration launch (which would otherwise
+    // rebuild it - a microsecond of dependent trig arithmetic in each of them)
+    if (mode == 0 && !ended && threadIdx.x < 64) {
+        float T[12], sc6[6];
+        build_transform(pose, (int)threadIdx.x, T, sc6);
+        if (threadIdx.x == 0 && !st->stalled) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) st->T[k] = T[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) st->sc[k] = sc6[k];
+            st->T_valid = 1;
+        }
+    }
 }
 
 // Observation hook: the device's sinf / cosf of n arguments (tests compare them with the host's libm).

@@ -873,6 +873,8 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     if (upd) {
         const float d2_5 = __uint_as_float(key_hi(fk[4]));
         const bool gated = complete && ((double)d2_5 < cp->gate_sq);                  // :1097
+        v4f old_plane = { NAN, 0.0f, 0.0f, 0.0f };
+        if (complete && changed && had5 && (ost & 3) != 0 && !HOOK) old_plane = planep[i];   // the plane of the tuple the lane leaves
         // The LS plane and its inlier test depend only on the ordered neighbour tuple, not on the pose: a point
         // that kept its tuple keeps its plane (and its verdict) bit for bit.
         int pst = (!changed && !(ablate & 32)) ? (ost & 3) : 0;
@@ -921,7 +923,18 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         slack = (slack > 0.0f && !tie56) ? slack : 0.0f;                              // also NaN -> 0
         const v4f cnew = { sx, sy, sz, slack };
         certp[i] = cnew;
-        const v4i anew = { __float_as_int(rn), pst | (complete ? 4 : 0) | (nbr_ok ? 8 : 0), nbr_ok ? nb_n : 0, __float_as_int(fminf(r7, rn)) };
+        // The tuple a lane leaves is kept with its plane (plane_alt / npos_alt, state bit 4): two nearly equidistant neighbours swap
+        // places back and forth with the micro-steps of the converged loop, and the certify kernels exchange the two planes
+        // instead of sending the lane here again.  (A kept pair stays valid whatever happens to the lane: a plane depends on
+        // nothing but its tuple.)
+        const bool keep_old = complete && changed && had5 && (ost & 3) != 0 && !HOOK;
+        if (keep_old) {
+            G((v4f*)cp->plane_alt)[i] = old_plane;
+#pragma unroll
+            for (int k = 0; k < 5; k++) G(cp->npos_alt)[(size_t)k * nq + i] = opos[k];
+        }
+        const v4i anew = { __float_as_int(rn), pst | (complete ? 4 : 0) | (nbr_ok ? 8 : 0) | (keep_old ? 16 : (ost & 16)), nbr_ok ? nb_n : 0,
+                           __float_as_int(fminf(r7, rn)) };
         auxp[i] = anew;
         if (complete && changed) {
 #pragma unroll
@@ -951,19 +964,17 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// pass 2: residual, weight, Jacobian row and the 28 products of one wave-table entry (:1125-1139, :1216-1239)
-// ------------------------------------------------------------------------------------------
-template <bool HOOK>
-__device__ __forceinline__ void linearise_point(const DevCtx* __restrict__ cp, const float (&T)[12], const float (&sc6)[6],
-                                                int i, float px, float py, float pz, const v4f pl, double (&acc)[kAcc])
+// residual, weight (:1125-1139) and Jacobian row (:1216-1234) of one point against its plane: keep = the point is a
+// correspondence (laserCloudOriFlag); cf = coeffSel; row / rhs = its line of matA / matB
+__device__ __forceinline__ bool linearise_row(const DevCtx* __restrict__ cp, const float (&T)[12], const float (&sc6)[6],
+                                              float px, float py, float pz, const v4f pl, float (&cf)[4], float (&row)[6], float& rhs)
 {
     const float sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
     const float sy = ((T[4] * px + T[5] * py) + T[6]  * pz) + T[7];
     const float sz = ((T[8] * px + T[9] * py) + T[10] * pz) + T[11];
     const bool fin = (fabsf(sx) < 3.0e38f) && (fabsf(sy) < 3.0e38f) && (fabsf(sz) < 3.0e38f);
     bool keep = false;
-    float cf[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    cf[0] = 0.0f; cf[1] = 0.0f; cf[2] = 0.0f; cf[3] = 0.0f;
     if (fin && pl.x == pl.x) {                                                        // gated, plane passed the inlier test
         const float pa = pl.x, pb = pl.y, pc = pl.z, pd = pl.w;
         const float pd2 = pa * sx + pb * sy + pc * sz + pd;                           // :1125
@@ -974,9 +985,36 @@ __device__ __forceinline__ void linearise_point(const DevCtx* __restrict__ cp, c
             keep = true;
         }
     }
+#pragma unroll
+    for (int a = 0; a < 6; a++) row[a] = 0.0f;
+    rhs = 0.0f;
+    if (keep) jacobian_row(sc6, px, py, pz, cf, row, rhs);
+    return keep;
+}
+
+// product number k of a correspondence's line (21 upper-triangular JtJ, 6 Jtr, the count), k a compile-time constant
+template <int K>
+__device__ __forceinline__ double line_product(const float (&row)[6], float rhs, bool keep)
+{
+    if (K == kAcc - 1) return keep ? 1.0 : 0.0;
+    if (K >= 21) return (double)row[K - 21 < 6 ? K - 21 : 0] * (double)rhs;
+    // (a, b), a <= b, is number a*6 - a(a-1)/2 + (b-a)
+    constexpr int a = K < 6 ? 0 : (K < 11 ? 1 : (K < 15 ? 2 : (K < 18 ? 3 : (K < 20 ? 4 : 5))));
+    constexpr int base = a * 6 - (a * (a - 1)) / 2;
+    constexpr int b = a + (K - base);
+    return (double)row[a < 6 ? a : 0] * (double)row[(b >= 0 && b < 6) ? b : 0];
+}
+
+// ------------------------------------------------------------------------------------------
+// pass 2: residual, weight, Jacobian row and the 28 products of one wave-table entry (:1125-1139, :1216-1239)
+// ------------------------------------------------------------------------------------------
+template <bool HOOK>
+__device__ __forceinline__ void linearise_point(const DevCtx* __restrict__ cp, const float (&T)[12], const float (&sc6)[6],
+                                                int i, float px, float py, float pz, const v4f pl, double (&acc)[kAcc])
+{
+    float cf[4], row[6], rhs;
+    const bool keep = linearise_row(cp, T, sc6, px, py, pz, pl, cf, row, rhs);
     if (keep) {
-        float row[6], rhs;
-        jacobian_row(sc6, px, py, pz, cf, row, rhs);
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 6; a++)
@@ -1030,30 +1068,88 @@ __device__ __forceinline__ void linearise_chunk(const DevCtx* __restrict__ cp, c
 // ------------------------------------------------------------------------------------------
 constexpr int kFused = 0, kCertify = 1, kSearch = 2;
 constexpr int kCertifyWaves = 4;       // waves per SIMD the certify kernel is built for (8-wave workgroups) ...
-constexpr int kCertifyWavesBig = 4;    // ... and in the 16-wave shape of large scans
+constexpr int kCertifyWavesBig = 4;
+constexpr int kCertifyLeanWaves = 8;   // the lean certify kernel: 64 registers
+constexpr int kCertifyLeanEpw = 2;     // ... two entries per wave: four waves write a row of eight    // ... and in the 16-wave shape of large scans
 constexpr int kFlagSolvePrev = 1;      // the prologue closes iteration launch-1 (fused loop)
 constexpr int kFlagAll = 2;            // kSearch: every workgroup, no worklist (launch 0 of a scan, observation hooks)
-// ---- wave reduction by recursive halving: at mask m a lane keeps one half of its sums and
-// hands the other half to lane^m, so 16+8+4+2+1 values cross instead of 5 x 28; after the
-// five steps lane l holds, in a[0], sum number l>>1 over its half-wave pair group, and one
-// full exchange with lane^1 completes it.  Fixed order: bitwise reproducible.
-__device__ __forceinline__ void wave_reduce_acc(const double (&acc)[kAcc], int lane, double* red_row /* [32] of this wave */)
+// ---- wave reduction by recursive halving, 16 sums at a time: at mask m a lane keeps one half of its sums and hands the
+// other half to lane^m, so 8+4+2+1 values cross instead of 4 x 16; after the four steps lane l holds, in a[0], sum number
+// l>>2 over the 16 lanes that share its two low bits, and two full exchanges complete it.  Fixed order: bitwise
+// reproducible.  The first two steps (12 of the 17 exchanges) are lane swaps in the vector unit, the rest go through LDS.  The 28 sums of the normal equations go through it in two batches of 14 (a batch is all a lean kernel
+// needs to hold: 32 registers).
+// one exchange of the halving at mask 32 / 16 without a shuffle: v_permlane32_swap trades the upper 32 lanes of its first
+// operand for the lower 32 of its second (v_permlane16_swap: odd 16-lane rows for even ones), after which every lane holds
+// the value it keeps in one register and the value it receives in the other - the same two numbers, the same one addition
+template <int M>
+__device__ __forceinline__ double halving_swap_add(double lo, double hi)
 {
-    double a[32];
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    const unsigned long long ul = (unsigned long long)__double_as_longlong(lo), uh = (unsigned long long)__double_as_longlong(hi);
+    v2u_ w0, w1;
+    if (M == 32) {
+        w0 = __builtin_amdgcn_permlane32_swap((unsigned)ul, (unsigned)uh, false, false);
+        w1 = __builtin_amdgcn_permlane32_swap((unsigned)(ul >> 32), (unsigned)(uh >> 32), false, false);
+    } else {
+        w0 = __builtin_amdgcn_permlane16_swap((unsigned)ul, (unsigned)uh, false, false);
+        w1 = __builtin_amdgcn_permlane16_swap((unsigned)(ul >> 32), (unsigned)(uh >> 32), false, false);
+    }
+    const double x = __longlong_as_double((long long)(((unsigned long long)w1.x << 32) | w0.x));
+    const double y = __longlong_as_double((long long)(((unsigned long long)w1.y << 32) | w0.y));
+    return x + y;
+}
+
+__device__ __forceinline__ void wave_reduce16(double (&a)[16], int lane, double* red16 /* 16 slots of this wave's row */)
+{
 #pragma unroll
-    for (int k = 0; k < 32; k++) a[k] = (k < kAcc) ? acc[k] : 0.0;
+    for (int j = 0; j < 8; j++) a[j] = halving_swap_add<32>(a[j], a[j + 8]);
 #pragma unroll
-    for (int h = 16, m = 32; h >= 1; h >>= 1, m >>= 1) {
+    for (int j = 0; j < 4; j++) a[j] = halving_swap_add<16>(a[j], a[j + 4]);
+#pragma unroll
+    for (int h = 2, m = 8; h >= 1; h >>= 1, m >>= 1) {
         const bool up = (lane & m) != 0;
 #pragma unroll
         for (int j = 0; j < h; j++) {
-            const double keepv = up ? a[j + h] : a[j];
-            const double sendv = up ? a[j] : a[j + h];
+            double lo = a[j], hi = a[j + h];
+            asm volatile("" : "+v"(lo), "+v"(hi));            // two values, not one dynamically indexed array element (a select chain per exchange)
+            const double keepv = up ? hi : lo;
+            const double sendv = up ? lo : hi;
             a[j] = keepv + __shfl_xor(sendv, m, 64);
         }
     }
+    a[0] += __shfl_xor(a[0], 2, 64);
     a[0] += __shfl_xor(a[0], 1, 64);
-    if ((lane & 1) == 0) red_row[lane >> 1] = a[0];
+    if ((lane & 3) == 0) red16[lane >> 2] = a[0];
+}
+
+constexpr int kAccHalf = kAcc / 2;     // sums per batch
+__device__ __forceinline__ void wave_reduce_acc(const double (&acc)[kAcc], int lane, double* red_row /* [32] of this wave */)
+{
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        double a[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) a[k] = (k < kAccHalf) ? acc[half * kAccHalf + k] : 0.0;
+        wave_reduce16(a, lane, red_row + 16 * half);
+    }
+}
+
+// the sums of one correspondence line per lane (a wave with a single entry), without holding all 28 at once
+template <int HALF>
+__device__ __forceinline__ void wave_reduce_line(const float (&row)[6], float rhs, bool keep, int lane, double* red_row)
+{
+    double a[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) a[k] = 0.0;
+    // 0.0 + p, as the accumulators of the other kernels see it
+    a[0] = 0.0 + line_product<HALF * kAccHalf + 0>(row, rhs, keep);   a[1] = 0.0 + line_product<HALF * kAccHalf + 1>(row, rhs, keep);
+    a[2] = 0.0 + line_product<HALF * kAccHalf + 2>(row, rhs, keep);   a[3] = 0.0 + line_product<HALF * kAccHalf + 3>(row, rhs, keep);
+    a[4] = 0.0 + line_product<HALF * kAccHalf + 4>(row, rhs, keep);   a[5] = 0.0 + line_product<HALF * kAccHalf + 5>(row, rhs, keep);
+    a[6] = 0.0 + line_product<HALF * kAccHalf + 6>(row, rhs, keep);   a[7] = 0.0 + line_product<HALF * kAccHalf + 7>(row, rhs, keep);
+    a[8] = 0.0 + line_product<HALF * kAccHalf + 8>(row, rhs, keep);   a[9] = 0.0 + line_product<HALF * kAccHalf + 9>(row, rhs, keep);
+    a[10] = 0.0 + line_product<HALF * kAccHalf + 10>(row, rhs, keep); a[11] = 0.0 + line_product<HALF * kAccHalf + 11>(row, rhs, keep);
+    a[12] = 0.0 + line_product<HALF * kAccHalf + 12>(row, rhs, keep); a[13] = 0.0 + line_product<HALF * kAccHalf + 13>(row, rhs, keep);
+    wave_reduce16(a, lane, red_row + 16 * HALF);
 }
 
 // the workgroup's partial row: the sums of its CNW waves, in wave order (after a barrier)
@@ -1062,9 +1158,10 @@ __device__ __forceinline__ void write_partial_row(const DevCtx* __restrict__ cp,
 {
     if (tid < kAcc) {
         const auto partial_row = G(cp->partials) + ((size_t)(launch & 1) * (size_t)cp->nblocks + b) * kAcc;   // slot launch & 1
-        double s = red[0][tid];
+        const int at = tid < kAccHalf ? tid : 16 + (tid - kAccHalf);        // (the two batches of wave_reduce_acc)
+        double s = red[0][at];
 #pragma unroll
-        for (int w = 1; w < CNW; w++) s += red[w][tid];
+        for (int w = 1; w < CNW; w++) s += red[w][at];
         partial_row[tid] = s;
     }
 }
@@ -1080,6 +1177,196 @@ __device__ __forceinline__ bool lane_needs(const float (&T)[12], float px, float
     const float ex = sx - cert.x, ey = sy - cert.y, ez = sz - cert.z;
     eps = sqrtf((ex * ex + ey * ey) + ez * ez) * 1.0001f + 1e-6f;
     return fin && !(!(ablate & 1) && (eps < cert.w));
+}
+
+// ------------------------------------------------------------------------------------------
+// k_certify_lean: the certify role for loops whose iterations are closed by k_finalize (the lockstep loop of a batch: its
+// grid is several rounds of workgroups deep, and how many of them a CU holds at once is what bounds a steady launch).
+// No close, no tile, one wave-table entry per wave, the sums formed 14 at a time: 64 registers, eight waves per SIMD.
+// A lane that fails its certificate is re-measured in line against its six front members (as the fused kernel does for
+// lanes without slack, but fetched on demand); a flip back to the previous order exchanges the kept planes.  Whatever that
+// does not settle - and any partition with more than one entry per wave - sends the workgroup to the search kernel.
+// ------------------------------------------------------------------------------------------
+// (EPW entries per wave: a workgroup of NW / EPW waves writes the row of NW entries - every entry reduced on its own, the
+// row summed in entry order, exactly as a workgroup of NW waves would - so that twice as many rows are in flight per CU.)
+template <int NW, int EPW, int MINW>
+__global__ __launch_bounds__(NW / EPW * 64, MINW) void k_certify_lean(const SlotTable tbl, int launch)
+{
+    static_assert(NW % EPW == 0, "whole entries per wave");
+    constexpr int NWL = NW / EPW;                              // waves of this workgroup
+    const DevCtx* __restrict__ cp = tbl.ctx[blockIdx.y];
+    const auto st = G(tbl.st[blockIdx.y]);
+    const int done = st->done, n_waves = st->n_waves;
+    if (done) return;
+    __shared__ double red[NW][32];
+    __shared__ float park[EPW == 2 ? NWL : 1][7][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nblocks = cp->nblocks;
+    const int nb_act = min((n_waves + NW - 1) / NW, nblocks);
+    const int b = (int)blockIdx.x;
+    if (b >= nb_act) return;
+    const int nq = cp->n_q;
+    const int ablate = cp->ablate;
+    const bool single = nb_act * NW >= n_waves;                // every wave of the partition has one entry at most
+    // everything the entries need is requested together (the second entry's plane only once the first is under way: registers);
+    // the entries are then taken one after the other by the same code (cur = the entry in hand)
+    static_assert(EPW == 1 || EPW == 2, "one or two entries per wave");
+    const auto tb = G((const int2*)cp->wave_table);
+    int2 chunkA = make_int2(0, 0), chunkB = make_int2(0, 0);
+    {
+        const int eA = wave * nb_act + b, eB = (wave + NWL) * nb_act + b;
+        if (eA < n_waves) { chunkA.x = tb[eA].x; chunkA.y = tb[eA].y; }
+        if (EPW == 2 && eB < n_waves) { chunkB.x = tb[eB].x; chunkB.y = tb[eB].y; }
+        chunkA.x = __builtin_amdgcn_readfirstlane(chunkA.x); chunkA.y = __builtin_amdgcn_readfirstlane(chunkA.y);
+        chunkB.x = __builtin_amdgcn_readfirstlane(chunkB.x); chunkB.y = __builtin_amdgcn_readfirstlane(chunkB.y);
+    }
+    float px = 0.0f, py = 0.0f, pz = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f;
+    v4f cert = { 0, 0, 0, 0 }, certB = { 0, 0, 0, 0 }, plane0 = { NAN, 0, 0, 0 };
+    if (lane < chunkA.y && chunkA.x + lane < nq) {
+        const int i = chunkA.x + lane;
+        px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];                      // pointOri (:1085)
+        cert = G((const v4f*)cp->cert)[i];
+        plane0 = G((const v4f*)cp->plane_cache)[i];
+    }
+    if (EPW == 2 && lane < chunkB.y && chunkB.x + lane < nq) {
+        const int i = chunkB.x + lane;
+        bx = G(cp->qx)[i]; by = G(cp->qy)[i]; bz = G(cp->qz)[i];
+        certB = G((const v4f*)cp->cert)[i];
+    }
+    // the transform of this launch's pose: left in the state block by k_finalize (or by the host for launch 0)
+    float T[12], sc6[6];
+    if (st->T_valid) {
+#pragma unroll
+        for (int k = 0; k < 12; k++) T[k] = st->T[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) sc6[k] = st->sc[k];
+    } else {
+        float pose[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) pose[k] = st->pose2[launch & 1][k];
+        build_transform(pose, lane, T, sc6);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) T[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(T[k])));
+#pragma unroll
+    for (int k = 0; k < 6; k++) sc6[k] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sc6[k])));
+
+    bool defer = !single;
+    int2 chunk = chunkA;
+#pragma unroll 1
+    for (int q = 0; q < EPW && single; q++) {
+        const int w = wave + q * NWL;                          // the wave of the row this entry belongs to
+        const int e = w * nb_act + b;
+        // (the products of the trig values in the Jacobian row are wave-uniform but live in vector registers - this part has no
+        // scalar float arithmetic - and hoisted out of this loop they cost twenty registers: keep them where they are used)
+#pragma unroll
+        for (int k = 0; k < 6; k++) asm volatile("" : "+s"(sc6[k]));
+        if (e >= n_waves) { if (lane < 32) red[w][lane] = 0.0; }
+        else {
+        const int i = chunk.x + lane;
+        const bool valid0 = lane < chunk.y && i < nq;
+        if (EPW == 2 && q == 1 && valid0) plane0 = G((const v4f*)cp->plane_cache)[i];
+        float sx, sy, sz, eps;
+        const bool need = lane_needs(T, px, py, pz, cert, valid0, ablate, sx, sy, sz, eps);
+        bool bad = false;
+        if (__builtin_expect(__ballot(need) != 0ull, 0)) {
+            // in-line re-measurement of the six front members (see the fused kernel); nothing is written unless the order flipped
+            // back to the tuple the lane had before.  (Rare: the second entry's point waits in LDS meanwhile, not in registers.)
+            if (EPW == 2) {
+                park[wave][0][lane] = bx; park[wave][1][lane] = by; park[wave][2][lane] = bz;
+                park[wave][3][lane] = certB.x; park[wave][4][lane] = certB.y; park[wave][5][lane] = certB.z; park[wave][6][lane] = certB.w;
+                asm volatile("" : "=v"(bx), "=v"(by), "=v"(bz));
+            }
+            bool okl = !need, flip = false;
+            int nk[5] = { 0, 0, 0, 0, 0 };                    // the re-measured order (positions in map_sorted)
+            v4i aux = { 0, 0, 0, 0 };
+            if (need && !(ablate & 3)) {
+                aux = G((const v4i*)cp->aux)[i];
+                const int nfr = min(max(aux.z, 0), kNbr);
+                okl = (aux.y & 12) == 12 && (aux.y & 3) != 0;      // tuple complete, neighbourhood valid, plane known
+                Top6k t;
+#pragma unroll
+                for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
+                {
+                    int front[6];
+#pragma unroll
+                    for (int j = 0; j < 6; j++) front[j] = G(cp->nbr)[(size_t)j * nq + i];
+                    const auto map = G((const v4f*)cp->map_sorted);
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        const bool on = okl && k < nfr;
+                        const v3f mm = *reinterpret_cast<gptr<const v3f>>(&map[on ? front[k] : 0]);
+                        const float dx = sx - mm.x, dy = sy - mm.y, dz = sz - mm.z;
+                        const float d2 = (dx * dx + dy * dy) + dz * dz;                 // L2_Simple order
+                        top6k_insert(t, on ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)front[k]) : kKeyInf);
+                    }
+                }
+                const float r = __int_as_float(aux.w) - eps;                            // everything outside the six is at least this far away
+                const float d2_5 = __uint_as_float(key_hi(t.key[4]));
+                okl = okl && key_hi(t.key[4]) < 0x7f800000u && ((double)d2_5 < cp->gate_sq) && (sqrtf(d2_5) + kCertMargin < r);
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    okl = okl && key_hi(t.key[k]) != key_hi(t.key[k + 1]);
+                    nk[k] = (int)key_lo(t.key[k]);
+                }
+                if (okl) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) flip = flip || nk[k] != G(cp->npos)[(size_t)k * nq + i];
+                }
+            }
+            if (__ballot(flip)) {
+                // the previous tuple's plane is kept: a flip back exchanges the two; any other order has to be fitted (search kernel)
+                bool back = flip && (aux.y & 16) != 0;
+                if (back) {
+#pragma unroll
+                    for (int k = 0; k < 5; k++) back = back && nk[k] == G(cp->npos_alt)[(size_t)k * nq + i];
+                }
+                if (back) {
+                    const v4f pl_new = G((const v4f*)cp->plane_alt)[i];
+                    G((v4f*)cp->plane_alt)[i] = plane0;                                 // what the lane had until now
+#pragma unroll
+                    for (int k = 0; k < 5; k++) {
+                        const int o = G(cp->npos)[(size_t)k * nq + i];
+                        G(cp->npos_alt)[(size_t)k * nq + i] = o;
+                        G(cp->npos)[(size_t)k * nq + i] = nk[k];
+                    }
+                    G((v4f*)cp->plane_cache)[i] = pl_new;
+                    plane0 = pl_new;
+                    // the stored certificate spoke of the old order: none from now on
+                    const v4f cnew = { cert.x, cert.y, cert.z, 0.0f };
+                    G((v4f*)cp->cert)[i] = cnew;
+                    const v4i anew = { aux.x, (aux.y & ~3) | ((pl_new.x == pl_new.x) ? 1 : 2) | 16, aux.z, aux.w };
+                    G((v4i*)cp->aux)[i] = anew;
+                }
+                okl = okl && (!flip || back);
+            }
+            bad = __ballot(!okl) != 0ull;
+            if (EPW == 2) {
+                wave_lds_sync();
+                bx = park[wave][0][lane]; by = park[wave][1][lane]; bz = park[wave][2][lane];
+                certB.x = park[wave][3][lane]; certB.y = park[wave][4][lane]; certB.z = park[wave][5][lane]; certB.w = park[wave][6][lane];
+            }
+        }
+        defer = defer || bad;
+        if (!bad) {
+            float cf[4], row[6], rhs;
+            const v4f pl = valid0 ? plane0 : v4f{ NAN, 0, 0, 0 };
+            const bool keep = linearise_row(cp, T, sc6, px, py, pz, pl, cf, row, rhs);   // (an idle lane: plane NaN, no line)
+            wave_reduce_line<0>(row, rhs, keep, lane, red[w]);
+            wave_reduce_line<1>(row, rhs, keep, lane, red[w]);
+        }
+        }
+        // the second entry takes the first one's place
+        chunk = chunkB; px = bx; py = by; pz = bz; cert = certB;
+    }
+    if (__syncthreads_or(defer ? 1 : 0)) {
+        if (tid == 0) {
+            const int slot = atomicAdd(cp->wl_count + (launch & 1), 1);
+            G(cp->wl_items)[(size_t)(launch & 1) * (size_t)nblocks + slot] = b;
+        }
+        return;
+    }
+    write_partial_row<NW>(cp, launch, b, tid, red);
 }
 
 // NW waves per workgroup; MINW waves per SIMD the kernel is built for (the register budget: 512 / MINW per lane);
@@ -1119,7 +1406,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     if (MODE == kSearch && !(flags & kFlagAll)) {
         const auto wlc = G(cp->wl_count);
         const int cnt = wlc[launch & 1];
-        if (b == 0 && tid == 0) wlc[(launch + 1) & 1] = 0;                  // the next launch's list starts empty (nobody reads or appends to it now)
+        if (b == 0 && tid == 0) { wlc[(launch + 1) & 1] = 0; st->deferred_total += cnt; }   // the next launch's list starts empty (nobody reads or appends to it now)
         if (b >= cnt) return;
         b = __builtin_amdgcn_readfirstlane(G(cp->wl_items)[(size_t)(launch & 1) * (size_t)nblocks + b]);
     } else if (MODE == kSearch) {
@@ -1158,8 +1445,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     // transPointAssociateToMap (:1069-1072) and the LM trig (:1170-1175). Launch 0 of a scan gets them
     // from the host (libm); later launches rebuild them from the pose: lanes 0..2 take one angle each
     // (glibc's sinf / cosf arithmetic, see glibc_sincosf).  With solve_prev the pose is first advanced by closing
-    // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.  The search kernel takes
-    // what the certify kernel of the same launch left in the state block.
+    // iteration launch-1 (LMOptimization's solve and update) right here, in every workgroup.  (The search kernel never
+    // closes: the certify kernel of the same launch or k_finalize has stored the pose of this launch.)
     Fragile frag;
 #pragma unroll
     for (int k = 0; k < 6; k++) frag.mm[k] = v3f{ 0.0f, 0.0f, 0.0f };
@@ -1169,11 +1456,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
         for (int k = 0; k < 12; k++) T[k] = st->T[k];
 #pragma unroll
         for (int k = 0; k < 6; k++) sc6[k] = st->sc[k];
-    } else if (MODE == kSearch) {
-#pragma unroll
-        for (int k = 0; k < 12; k++) T[k] = st->T2[launch & 1][k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) sc6[k] = st->sc2[launch & 1][k];
     } else {
         float pose[6];
         if (solve_prev) {
@@ -1214,23 +1496,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
 #pragma unroll
             for (int k = 0; k < 6; k++) pose[k] = st->pose2[launch & 1][k];
         }
-        const float ang = (lane == 0) ? pose[2] : ((lane == 1) ? pose[1] : pose[0]);   // lane 0: yaw, 1: pitch, 2+: roll
-        float snf, csf;
-        glibc_sincosf_both(ang, snf, csf);                                         // what the host's libm would return
-        const float B = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 0)), A = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 0));
-        const float D = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 1)), C = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 1));
-        const float F = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(snf), 2)), E = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(csf), 2));
-        const float DE = D * E, DF = D * F;
-        T[0] = A * C; T[1] = A * DF - B * E; T[2]  = B * F + A * DE; T[3]  = pose[3];
-        T[4] = B * C; T[5] = A * E + B * DF; T[6]  = B * DE - A * F; T[7]  = pose[4];
-        T[8] = -D;    T[9] = C * F;          T[10] = C * E;          T[11] = pose[5];
-        sc6[0] = B; sc6[1] = A; sc6[2] = D; sc6[3] = C; sc6[4] = F; sc6[5] = E;
-        if (MODE == kCertify && blockIdx.x == 0 && tid == 0) {                      // for the search kernel of this launch
-#pragma unroll
-            for (int k = 0; k < 12; k++) st->T2[launch & 1][k] = T[k];
-#pragma unroll
-            for (int k = 0; k < 6; k++) st->sc2[launch & 1][k] = sc6[k];
-        }
+        build_transform(pose, lane, T, sc6);
     }
     // wave-uniform by construction: into scalar registers, out of the way of everything below
 #pragma unroll
@@ -1243,8 +1509,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     double acc[kAcc];                                       // zeroed only after the association: nothing of pass 2 is live during pass 1
     bool defer = false;                                     // kCertify: this wave holds a lane that needs the search kernel
 
-    if (MODE == kSearch) {
-        // ---- the search kernel: the waves of row b in rounds of NW; per wave the association of all its entries, then the residuals
+    if (MODE == kSearch && CNW != NW) {
+        // ---- the search kernel on a partition of wider workgroups: the waves of row b in rounds of NW; per wave the association of
+        // all its entries, then the residuals (on its own partition it runs the fused kernel's path below)
         for (int r = 0; r < CNW / NW; r++) {
             const int w = r * NW + wave;
             e0 = w * nb_act + b;

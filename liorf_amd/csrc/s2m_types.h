@@ -46,8 +46,8 @@ struct DevState {
     int32_t stalled;      // n_sel < min_corr: every further iteration is the same no-op
     int32_t n_waves;      // wave-table entries of the resident scan (copied in by k_set_state)
     int32_t T_valid;      // 1: T/sc were set by the host (launch 0); 0: k_register rebuilds them from pose2
-    float T2[2][12];      // what the certify kernel of launch L built from pose2[L & 1], for the search kernel of the same launch
-    float sc2[2][6];
+    int32_t deferred_total; // diagnostics: workgroups the certify kernel handed to the search kernel, summed over the loop
+    int32_t pad_;
 };
 
 // Everything a kernel needs, in device memory so a captured graph stays valid when

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device",
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
     "s2m_optimize_batch", "s2m_batch_set_scan", "s2m_batch_set_scans", "s2m_optimize_batch_launch", "s2m_optimize_batch_collect", "s2m_batch_get_trace",
-    "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing",
+    "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing", "s2m_debug_deferred",
     "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile", "s2m_debug_time_steady", "s2m_time_loop_launches",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
     "s2m_transform_cloud",
@@ -140,6 +140,7 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_surf_optimization.argtypes = [vp, fp, C.POINTER(C.c_int32), fp, C.POINTER(C.c_uint8), fp]
     L.s2m_normal_eq.argtypes = [vp, fp, fp, fp, C.POINTER(C.c_int32)]
     L.s2m_last_timing.argtypes = [vp, fp, fp, fp]
+    L.s2m_debug_deferred.argtypes = [vp, C.c_int]
     L.s2m_time_iteration_kernel.argtypes = [vp, fp, C.c_int, fp]
     L.s2m_time_iterations.argtypes = [vp, fp, C.c_int, fp, C.c_int]
     L.s2m_debug_wave_profile.argtypes = [vp, fp, C.c_int, C.POINTER(C.c_uint64), C.c_size_t]

@@ -193,3 +193,56 @@ def test_reused_handle_gives_bitwise_the_loop_of_a_fresh_one_that_searches_every
         g.setInputCloud(synth.to_xyzi(small["map"]))
         assert trace_of(g, small, pose) == ref[k], k
     g.close()
+
+
+@pytest.mark.parametrize("name", ["small", "kitti64", "ouster128"])
+def test_certify_plus_search_kernels_give_bitwise_the_loop_of_the_fused_kernel(name, monkeypatch):
+    """S2M_SPLIT=1: every iteration as certify kernel + search kernel over the worklist of deferred workgroups (launch 0:
+    the search kernel over everything).  A workgroup's partial row is the same sum whichever kernel writes it, so the
+    trace must be bitwise that of the fused kernel - with certificates on and off, early exit on and off."""
+    cfg = synth.make_config(name)
+    for early_exit in (0, 1):
+        monkeypatch.setenv("S2M_SPLIT", "0")
+        ref = _loop(cfg, "0", monkeypatch, early_exit)
+        monkeypatch.setenv("S2M_SPLIT", "1")
+        for ablate in ("0", "3"):
+            got = _loop(cfg, ablate, monkeypatch, early_exit)
+            assert got[:3] == ref[:3], (ablate, got[:3], ref[:3])
+            assert np.array_equal(got[4], ref[4]), ablate
+            for k in (3, 5, 6):
+                assert np.array_equal(got[k].view(np.uint32), ref[k].view(np.uint32)), (ablate, k)
+
+
+def test_lockstep_batch_with_the_lean_certify_kernel_equals_separate_calls_bitwise(monkeypatch):
+    """S2M_SPLIT=2: a batch too large for the fused close runs k_certify_lean (64 registers, two batches of 14 sums) + the
+    search kernel + k_finalize per iteration; S2M_LOCKSTEP=0: the scans as branches of the graph.  Either way every slot's
+    trace is bitwise the trace of a separate call."""
+    cfgs = [synth.make_config("small", scan_index=k) for k in range(6)]
+    m = synth.to_xyzi(cfgs[0]["map"])
+    scans = [synth.to_xyzi(c["scan"]) for c in cfgs]
+    scans[3] = scans[3][:7001]
+    poses = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
+    monkeypatch.setenv("S2M_SPLIT", "0")
+    solo = []
+    for s_, p_ in zip(scans, poses):
+        g = s2m.MapOptimizationS2M()
+        g.setInputCloud(m)
+        r = g.optimize(s_, p_)
+        solo.append((np.array(r.pose, np.float32), r.iters_run, np.array([t.pose[:] for t in g.trace()], np.float32)))
+        g.close()
+    for env in ({"S2M_SPLIT": "2", "S2M_FUSE_MAX": "0"}, {"S2M_SPLIT": "2", "S2M_FUSE_MAX": "0", "S2M_LEAN_EPW": "1"},
+                {"S2M_SPLIT": "0", "S2M_LOCKSTEP": "0"}, {"S2M_SPLIT": "1"}):
+        for k in ("S2M_SPLIT", "S2M_FUSE_MAX", "S2M_LEAN_EPW", "S2M_LOCKSTEP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        gpu = s2m.MapOptimizationS2M()
+        gpu.setInputCloud(m)
+        for rep in range(2):
+            out, res = gpu.optimizeBatch(scans, poses)
+            for b in range(len(scans)):
+                assert res[b].iters_run == solo[b][1], (env, b)
+                assert np.array_equal(out[b].view(np.uint32), solo[b][0].view(np.uint32)), (env, b)
+                tr = np.array([t.pose[:] for t in gpu.batchTrace(b)], np.float32)
+                assert tr.shape == solo[b][2].shape and np.array_equal(tr.view(np.uint32), solo[b][2].view(np.uint32)), (env, b)
+        gpu.close()

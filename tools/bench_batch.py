@@ -43,6 +43,7 @@ for early in EARLY:
                "lm_iterations_per_batch": iters, "lm_iterations_per_s": round(iters / t, 1), "scans_per_s": round(B / t, 1),
                "algorithmic_GBps_per_iteration_slot": round(b_alg * (iters / B) / t / 1e9, 2),
                "frac_of_hbm_peak": round(b_alg * (iters / B) / t / 8.0e12, 5),
+               "deferred_workgroups_per_scan": [int(eng.lib.s2m_debug_deferred(eng.h, b)) for b in range(B)],
                "pose_err_m_max": float(max(np.abs(p[b][3:] - cfgs[b]["pose_gt"][3:]).max() for b in range(B)))}
         out["batches"].append(rec)
         print(json.dumps(rec), flush=True)
