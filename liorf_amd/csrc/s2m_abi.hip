@@ -106,6 +106,7 @@ struct s2m_context {
     hipEvent_t ev_a2 = nullptr, ev_b2 = nullptr;
     int  split_mode = -1;              // env S2M_SPLIT: 1 = every loop runs certify + search kernels, 0 = every loop the fused kernel, default: split for the
                                        // scan slots of a batch and for 16-wave workgroups (large scans), fused for a single small scan
+    bool tune_env = false;             // S2M_TUNE given: the thresholds below are not derived from the workgroup shape
     int  lean_epw = 2;                 // env S2M_LEAN_EPW=1: one entry per wave in the lean certify kernel (A/B measurements)
     bool lean_certify = true;          // env S2M_LEAN=0: the certify role by the general kernel even where the 64-register one applies
     int  batch_entries = 1;            // env S2M_BATCH_ENTRIES: wave-table entries per wave in the scan slots of a batch (fewer, longer-running workgroups)
@@ -343,6 +344,9 @@ int scan_slot_prepare(s2m_context* h, const void* pts, size_t n, size_t stride, 
     nblocks = std::min((table_cap + wpb - 1) / wpb, (wpb == NW && h->parent) ? kMaxBlocks : kMaxBlocks / 2);
     if (h->parent && h->batch_entries > 1) nblocks = std::max((nblocks + h->batch_entries - 1) / h->batch_entries, 1);   // a batch slot: several entries per wave
     h->hctx.wpb = wpb;
+    // cutting a dense first-launch pass to 32 lanes pays in the 8-wave shape (kitti64: launch 0 89 -> 69 us); the 128-register
+    // build of the 16-wave shape loses more to the extra passes than it gains (ouster128 160 -> 182 us, dense1m 318 -> 345 us)
+    if (!h->tune_env) { h->hctx.tune[0] = (wpb == NW) ? kSplitRaw32 : (1 << 30); h->hctx.tune[1] = 1 << 30; }
     h->hctx.nblocks = nblocks;
     h->hctx.table_cap = table_cap;
     h->ctx_dirty = true;
@@ -835,6 +839,8 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->hctx.trace = reinterpret_cast<s2m_iter_trace*>(h->state.as<DevState>() + 1);
     params_to_ctx(h, prm);
     if (const char* e = getenv("S2M_ABLATE")) h->hctx.ablate = atoi(e);
+    h->hctx.tune[0] = kSplitRaw32; h->hctx.tune[1] = kSplitRaw16;
+    if (const char* e = getenv("S2M_TUNE")) { (void)sscanf(e, "%d,%d,%d,%d", &h->hctx.tune[0], &h->hctx.tune[1], &h->hctx.tune[2], &h->hctx.tune[3]); h->tune_env = true; }
     h->ctx_dirty = true;
     if (upload_ctx(h) != S2M_OK) return bail(S2M_ERR_HIP);
     *out = h;
@@ -1052,6 +1058,7 @@ int ensure_kids(s2m_context* h, int n)
         if (rc) return fail(h, rc, "batch: could not create a scan slot");
         k->parent = h;
         k->hctx.ablate = h->hctx.ablate;
+        memcpy(k->hctx.tune, h->hctx.tune, sizeof(h->hctx.tune));
         {   // the slot's loop state and trace live in the parent's block
             constexpr size_t kStride = sizeof(DevState) + sizeof(s2m_iter_trace) * kMaxIter;
             if (!h->kid_states.p) {

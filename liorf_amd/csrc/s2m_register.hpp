@@ -62,6 +62,8 @@ constexpr int   kWalkLanes = 64;       // a wave whose tile overflowed serves up
 constexpr int   kNbr = kNbrCap;        // neighbourhood capacity (map positions per scan point)
 constexpr int   kLevels = 6;           // radii a search counts against at once
 constexpr float kFragileSlack = 3e-5f; // a certificate with less slack than this may well fail in the steady state of the loop: such a lane prefetches
+constexpr int   kSplitRaw32 = 220;     // raw box points above which a tile pass of more than 32 lanes is cut to 32 lanes (consecutive lanes are neighbours: the box and
+constexpr int   kSplitRaw16 = 1 << 30; // the tile shrink, and the idle lanes share the sweeps) - and of more than 16 lanes to 16
 constexpr int   kServeLanes = 4;       // up to this many searching lanes are served one by one instead of staging a tile
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));
@@ -260,7 +262,8 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     // least r_out - (distance moved since) away: if that is beyond the new 5th member the tuple is proved; if it is
     // beyond the gate and fewer than 5 members are inside the gate, "not gated" is proved.
     {
-        const bool ev = need && nbr_ok && !(ablate & 2);
+        // (a lane that moved farther than its neighbourhood reaches cannot prove anything from it: it does not fetch the members)
+        const bool ev = need && nbr_ok && !(ablate & 2) && (r_out - eps > 0.0f);
         if (__ballot(ev)) {
             const int nmax = wave_max_i32(ev ? nb_n : 0);
             // A neighbourhood is stored with its six nearest members in front.  Those six first (positions, then the six
@@ -473,6 +476,11 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             const int ptot = __builtin_amdgcn_readlane(wave_incl_scan_i32(len), 63);
             if (HOOK) prof.raw += ptot;
             if (ptot > kTileRaw) { tile = false; if (HOOK) prof.why = 2; break; }
+            // a dense box under a wide pass: both sweeps cost lanes x tile points - half the lanes see a smaller box, and the
+            // other half of the wave shares their sweeps
+            // (lanes with a tuple to start from count against tight radii and list few candidates: measured, the cut does not pay there)
+            if (__ballot(act && has_prior) == 0ull &&
+                ((nA > 32 && ptot > cp->tune[0]) || (nA > 16 && nA <= 32 && ptot > cp->tune[1]))) { tile = false; if (HOOK) prof.why = 4; break; }
             // ---- stage through the filter: 16 lanes per row, 8 rows in flight per pass; a point
             // enters the tile only if it lies inside the lanes' point box grown by the largest radius.
             // Rows nobody marked, and marked rows that are empty, are squeezed out first (through LDS): every
