@@ -171,6 +171,15 @@ int  s2m_batch_set_scans(s2m_handle h, int n_scans, const void* const* scans, co
 int  s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses);
 int  s2m_optimize_batch_collect(s2m_handle h, int n_scans, float* poses, const s2m_imu_init* imu, s2m_result* out);
 int  s2m_batch_get_trace(s2m_handle h, int slot, s2m_iter_trace* out, int cap);
+/* A stream of scans against the resident map, one in flight per slot: slot k's preparation (scan ordering, wave table) and its
+ * loop run on slot k's own stream, so the preparation of scan i+1 in one slot overlaps the LM loop of scan i in the other - the
+ * reference does downsampleCurrentScan() and scan2MapOptimization() strictly one after the other (:257-265).  Typical use:
+ *     s2m_slot_set_scan(h, 0, scan0 ..);
+ *     for i:  s2m_slot_optimize_launch(h, i & 1, guess_i);  s2m_slot_set_scan(h, (i + 1) & 1, scan_{i+1} ..);  s2m_slot_optimize_collect(h, i & 1, ..)
+ * Every result is bitwise that of s2m_optimize on the same scan.  The map must not be replaced while a slot is in flight. */
+int  s2m_slot_set_scan(s2m_handle h, int slot, const void* pts, size_t n, size_t stride_bytes, int on_device);
+int  s2m_slot_optimize_launch(s2m_handle h, int slot, const float pose[6]);
+int  s2m_slot_optimize_collect(s2m_handle h, int slot, float pose[6], const s2m_imu_init* imu, s2m_result* out);
 
 /* Per-iteration records of the last optimize call; returns the count (<= cap). */
 int  s2m_get_trace(s2m_handle h, s2m_iter_trace* out, int cap);

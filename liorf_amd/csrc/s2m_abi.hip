@@ -88,6 +88,7 @@ struct s2m_context {
     // loop state + trace of every slot in one block (device) with a pinned mirror: one copy brings all of a batch's results back
     DevBuf kid_states;
     unsigned char* h_kid_states = nullptr;
+    bool slot_mode = false;            // (a slot running a loop of its own on its own stream: s2m_slot_optimize_*)
     bool state_borrowed = false;       // (a slot: `state` and `h_state` point into the parent's blocks)
     std::map<std::vector<int>, hipGraphExec_t> batch_graphs;
     unsigned long long map_epoch = 0;     // bumped by every s2m_set_map: children re-adopt the index when it changed
@@ -511,7 +512,7 @@ LoopShape shape_of(s2m_context* h)
     sh.tbl.ctx[0] = h->dctx.as<DevCtx>();
     sh.tbl.st[0] = h->state.as<DevState>();
     sh.nslots = 1; sh.nblocks = h->hctx.nblocks; sh.table_cap = h->hctx.table_cap; sh.wpb = h->hctx.wpb;
-    sh.batch = h->parent != nullptr;
+    sh.batch = h->parent != nullptr && !h->slot_mode;
     sh.split = h->split_mode == 1;
     return sh;
 }
@@ -963,7 +964,7 @@ int s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu, s
     if (!r.skipped) {
         S2M_HIP(h, hipSetDevice(h->device));
         S2M_HIP(h, hipStreamSynchronize(h->stream));
-        if (h->parent) h->t_optimize_ms = h->parent->t_optimize_ms;      // a slot of a batch: the batch was timed as a whole
+        if (h->parent && !h->slot_mode) h->t_optimize_ms = h->parent->t_optimize_ms;      // a slot of a batch: the batch was timed as a whole
         else S2M_HIP(h, hipEventElapsedTime(&h->t_optimize_ms, h->ev_a, h->ev_b));
         if (h->seg_pending && !h->h_state[1].done) {
             // the first range did not converge: the rest of the loop
@@ -1194,6 +1195,43 @@ int s2m_batch_set_scans(s2m_handle h, int n_scans, const void* const* scans, con
     }
     if (!on_device) S2M_HIP(h, hipStreamSynchronize(h->stream));       // the callers' buffers are free again
     return S2M_OK;
+}
+
+// ---- a stream of scans: slot k's preparation and loop run on slot k's own stream, so that the ordering of scan i+1 (slot B)
+// overlaps the LM loop of scan i (slot A) - the reference does the two strictly one after the other (:257-265) ----------
+int s2m_slot_set_scan(s2m_handle h, int slot, const void* pts, size_t n, size_t stride_bytes, int on_device)
+{ return s2m_batch_set_scan(h, slot, pts, n, stride_bytes, on_device); }
+
+int s2m_slot_optimize_launch(s2m_handle h, int slot, const float pose[6])
+{
+    if (!h || slot < 0 || slot >= (int)h->kids.size() || !pose) return S2M_ERR_INVALID_ARG;
+    s2m_context* k = h->kids[(size_t)slot];
+    if (!k->have_scan) return fail(h, S2M_ERR_NO_SCAN, "s2m_slot_set_scan has not been called for this slot");
+    S2M_HIP(h, hipSetDevice(h->device));
+    int rc;
+    if (!same_params_but_stream(k->prm, h->prm)) {
+        s2m_params p = h->prm;
+        p.stream = k->prm.stream;
+        if ((rc = s2m_set_params(k, &p))) return fail(h, rc, k->err.c_str());
+    }
+    h->prep_pending[(size_t)slot] = 0;                       // (the preparation is ahead of the loop on the same stream)
+    k->stream = h->branch_streams[(size_t)slot];
+    k->slot_mode = true;
+    rc = adopt_map(h, k);
+    if (!rc) rc = s2m_optimize_launch(k, pose);
+    k->stream = h->stream;
+    return rc ? fail(h, rc, k->err.c_str()) : S2M_OK;
+}
+
+int s2m_slot_optimize_collect(s2m_handle h, int slot, float pose[6], const s2m_imu_init* imu, s2m_result* out)
+{
+    if (!h || slot < 0 || slot >= (int)h->kids.size() || !pose) return S2M_ERR_INVALID_ARG;
+    s2m_context* k = h->kids[(size_t)slot];
+    k->stream = h->branch_streams[(size_t)slot];
+    const int rc = s2m_optimize_collect(k, pose, imu, out);
+    k->stream = h->stream;
+    k->slot_mode = false;
+    return rc ? fail(h, rc, k->err.c_str()) : S2M_OK;
 }
 
 int s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses)

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "s2m_version", "s2m_default_params", "s2m_create", "s2m_destroy", "s2m_last_error", "s2m_set_params", "s2m_get_params",
     "s2m_set_map", "s2m_set_map_device", "s2m_set_scan", "s2m_set_scan_device",
     "s2m_optimize", "s2m_optimize_resident", "s2m_optimize_launch", "s2m_optimize_collect",
-    "s2m_optimize_batch", "s2m_batch_set_scan", "s2m_batch_set_scans", "s2m_optimize_batch_launch", "s2m_optimize_batch_collect", "s2m_batch_get_trace",
+    "s2m_optimize_batch", "s2m_batch_set_scan", "s2m_batch_set_scans", "s2m_slot_set_scan", "s2m_slot_optimize_launch", "s2m_slot_optimize_collect", "s2m_optimize_batch_launch", "s2m_optimize_batch_collect", "s2m_batch_get_trace",
     "s2m_get_trace", "s2m_surf_optimization", "s2m_normal_eq", "s2m_last_timing", "s2m_debug_deferred",
     "s2m_time_iteration_kernel", "s2m_time_iterations", "s2m_make_scancontext", "s2m_debug_wave_profile", "s2m_debug_time_steady", "s2m_time_loop_launches",
     "s2m_voxel_downsample", "s2m_voxel_downsample_device", "s2m_downsample_scan", "s2m_extract_cloud",
@@ -133,6 +133,9 @@ def load_library(path: str | None = None) -> C.CDLL:
     L.s2m_get_trace.argtypes = [vp, C.POINTER(IterTrace), C.c_int]
     L.s2m_optimize_batch.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_size_t), C.c_size_t, fp, C.POINTER(ImuInit), C.POINTER(Result)]
     L.s2m_batch_set_scan.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.s2m_slot_set_scan.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_size_t, C.c_int]
+    L.s2m_slot_optimize_launch.argtypes = [vp, C.c_int, fp]
+    L.s2m_slot_optimize_collect.argtypes = [vp, C.c_int, fp, C.POINTER(ImuInit), C.POINTER(Result)]
     L.s2m_batch_set_scans.argtypes = [vp, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int]
     L.s2m_optimize_batch_launch.argtypes = [vp, C.c_int, fp]
     L.s2m_optimize_batch_collect.argtypes = [vp, C.c_int, fp, C.POINTER(ImuInit), C.POINTER(Result)]
@@ -392,6 +395,26 @@ class MapOptimizationS2M:
         else:
             a, n, st = _records(scan)
             self._check(self.lib.s2m_batch_set_scan(self.h, slot, a.ctypes.data, n, st, 0), "s2m_batch_set_scan")
+
+    # -- a stream of scans: preparation of the next scan overlaps the loop of the current one (two slots) ------
+    def slotSetScan(self, slot: int, scan=None, device_ptr=None):
+        if device_ptr is not None:
+            ptr, n, st = device_ptr
+            self._check(self.lib.s2m_slot_set_scan(self.h, slot, C.c_void_p(ptr), n, st, 1), "s2m_slot_set_scan")
+        else:
+            a, n, st = _records(scan)
+            self._check(self.lib.s2m_slot_set_scan(self.h, slot, a.ctypes.data, n, st, 0), "s2m_slot_set_scan")
+
+    def slotLaunch(self, slot: int, pose):
+        p = np.ascontiguousarray(pose, np.float32).reshape(6)
+        self._check(self.lib.s2m_slot_optimize_launch(self.h, slot, _fp(p)), "s2m_slot_optimize_launch")
+
+    def slotCollect(self, slot: int, imu=None):
+        r = Result()
+        p = np.zeros(6, np.float32)
+        self._check(self.lib.s2m_slot_optimize_collect(self.h, slot, _fp(p), C.byref(imu) if imu is not None else None, C.byref(r)),
+                    "s2m_slot_optimize_collect")
+        return p, r
 
     def batchSetScans(self, scans=None, device_ptrs=None):
         """Install slots 0 .. n-1 at once (s2m_batch_set_scans): host records, or device_ptrs=[(ptr, n, stride_bytes), ...]."""

@@ -118,3 +118,28 @@ def test_batch_of_eight_kitti64_scans(cfg_kitti64):
         assert res[b].converged == 1 and res[b].iters_run < 30
         assert np.abs(out[b][3:] - cfgs[b]["pose_gt"][3:]).max() < 0.03
     gpu.close()
+
+
+def test_stream_of_scans_through_two_slots_equals_separate_calls_bitwise():
+    """s2m_slot_*: the preparation of scan i+1 (slot B, its own stream) overlaps the loop of scan i (slot A); every result and
+    trace is bitwise that of s2m_optimize on the same scan - early exit on (two-range loop) and off."""
+    cfgs = [synth.make_config("small", scan_index=k) for k in range(6)]
+    m = synth.to_xyzi(cfgs[0]["map"])
+    scans = [synth.to_xyzi(c["scan"]) for c in cfgs]
+    scans[2] = scans[2][:6001]
+    poses = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
+    for early in (1, 0):
+        solo = [_solo(m, s, p, early_exit=early) for s, p in zip(scans, poses)]
+        gpu = s2m.MapOptimizationS2M(early_exit=early)
+        gpu.setInputCloud(m)
+        gpu.slotSetScan(0, scans[0])
+        for i in range(len(scans)):
+            gpu.slotLaunch(i & 1, poses[i])
+            if i + 1 < len(scans):
+                gpu.slotSetScan((i + 1) & 1, scans[i + 1])
+            p, r = gpu.slotCollect(i & 1)
+            assert (r.iters_run, r.converged, r.is_degenerate, r.n_sel_last, r.skipped) == solo[i][1], (early, i)
+            assert np.array_equal(p.view(np.uint32), solo[i][0].view(np.uint32)), (early, i)
+            tr = np.array([t.pose[:] for t in gpu.batchTrace(i & 1)], np.float32)
+            assert tr.shape == solo[i][3].shape and np.array_equal(tr.view(np.uint32), solo[i][3].view(np.uint32)), (early, i)
+        gpu.close()
