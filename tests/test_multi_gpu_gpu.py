@@ -48,6 +48,69 @@ def test_cpp_driver_registers_a_batch_and_gathers_with_rccl(tmp_path, cfg_tiny):
         orc.close()
 
 
+def test_cpp_driver_is_a_throughput_path(tmp_path, cfg_kitti64):
+    """The timed region of s2m_multi_gpu holds the registrations and the one all-gather, nothing else (persistent worker per
+    device, scans resident, one library call per shard): with one kitti64 scan on the one device its time per scan is within
+    10 % of what bench.py times as a step (set scan, 30 LM iterations, collect) in this process; with eight scans on the
+    device (the shard runs as one lockstep batch) a scan costs less than half of that."""
+    import time
+    import torch
+    exe = os.path.join(ROOT, "liorf_amd", "host", "s2m_multi_gpu")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "liorf_amd", "host")])
+    cfgs = [cfg_kitti64] + [synth.make_config("kitti64", scan_index=k) for k in range(1, 8)]
+    m = synth.to_xyzi(cfg_kitti64["map"])
+    (tmp_path / "map.bin").write_bytes(m.tobytes())
+    lines = []
+    for k, c in enumerate(cfgs):
+        (tmp_path / f"scan{k}.bin").write_bytes(synth.to_xyzi(c["scan"]).tobytes())
+        lines.append(str(tmp_path / f"scan{k}.bin") + " " + " ".join("%.9g" % v for v in c["pose_init"]))
+    (tmp_path / "one.txt").write_text(lines[0] + "\n")
+    (tmp_path / "eight.txt").write_text("\n".join(lines) + "\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(manifest):
+        out = subprocess.run([exe, "1", str(tmp_path / "map.bin"), str(tmp_path / manifest), "30", "0"], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-2000:]
+        tail = out.stdout.strip().splitlines()[-1].split()
+        return float(tail[tail.index("seconds_per_scan") + 1]), [l.split() for l in out.stdout.splitlines() if l.startswith("scan ")]
+
+    # the reference figure: bench.py's step, early exit off, inputs resident
+    dev = torch.device("cuda", 0)
+    d_map = torch.from_numpy(m).to(dev)
+    d_scan = torch.from_numpy(synth.to_xyzi(cfg_kitti64["scan"])).to(dev)
+    eng = s2m.MapOptimizationS2M(early_exit=0)
+    eng.setInputCloudDevice(d_map.data_ptr(), m.shape[0], 32)
+    def step():
+        eng.setScanDevice(d_scan.data_ptr(), d_scan.shape[0], 32)
+        eng.launch(cfg_kitti64["pose_init"])
+        return eng.collect()
+    for _ in range(5):
+        r = step()
+    ts = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r = step()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / 20)
+    step_s = float(np.median(ts))
+    eng.close()
+
+    # (the driver runs with early exit off here, as the step above does: 30 iterations per scan on both sides)
+    one_s, rows1 = run("one.txt")
+    eight_s, rows8 = run("eight.txt")
+    assert len(rows1) == 1 and len(rows8) == 8
+    it1 = int(rows1[0][5])
+    assert it1 == 30
+    print("bench step %.3f ms (30 iterations); driver: one scan %.3f ms (%d iterations), eight scans %.3f ms per scan" % (step_s * 1e3, one_s * 1e3, it1, eight_s * 1e3))
+    assert one_s <= 1.10 * step_s, (one_s, step_s)
+    assert eight_s <= 0.5 * step_s, (eight_s, step_s)
+    # the single scan and slot 0 of the batch are the same registration, bit for bit
+    assert rows1[0][5:] == rows8[0][5:]
+
+
 def test_record_gatherer_device_branch_under_nccl(cfg_tiny):
     import torch
     import torch.distributed as dist
