@@ -83,7 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--cpu-scans", type=int, default=10)
-    ap.add_argument("--batch", action="store_true", help="also time 2, 4 and 8 scans in flight against one map (s2m_optimize_batch)")
+    ap.add_argument("--no-batch", action="store_true", help="skip the side figures: 2, 4 and 8 scans in flight against one map (s2m_optimize_batch) and the pipelined stream of scans (s2m_slot_*)")
     ap.add_argument("--print-launch", action="store_true", help="print the command that would start the ranks and exit (no GPU call)")
     return ap.parse_args(argv)
 
@@ -129,6 +129,11 @@ def main(argv=None):
     args = parse_args(argv)
     start_ranks_if_asked(args, argv)
 
+    # HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), round-robin in creation order; two
+    # streams that land on one queue run strictly one after the other.  This process creates several engines (each with its
+    # stream, the pipelined ones with two slot streams more): with 4 queues the slot streams of the pipelined figure may share
+    # a queue and lose their overlap (measured: 0.628 -> 0.667 ms per scan, tools/experiments/exp15.py); 8 queues keep them apart.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from liorf_amd import batch, s2m, synth
@@ -275,27 +280,52 @@ def main(argv=None):
             e2.optimize(h_scans[k], cfgs[k]["pose_init"])
             th.append(time.perf_counter() - t1)
         early["ms_per_scan_host_buffers_early_exit"] = round(1e3 * float(np.median(th[2:])), 4)
-        # ---- several scans against the same map in one graph (BASELINE config 4 on one GPU) ---------------------------
+        # ---- a stream of scans through two slots: the preparation of scan i+1 overlaps the loop of scan i (s2m_slot_*) -----
+        if not args.no_batch:
+            for ee in (0, 1):
+                engs = s2m.MapOptimizationS2M(device_id=local_rank, early_exit=ee)      # (an engine of its own, as tools/bench_stream.py has)
+                engs.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
+                def stream(n):
+                    engs.slotSetScan(0, device_ptr=(d_scans[0].data_ptr(), n_q, 32))
+                    for i in range(n):
+                        engs.slotLaunch(i & 1, cfgs[i % N_SCANS]["pose_init"])
+                        engs.slotSetScan((i + 1) & 1, device_ptr=(d_scans[(i + 1) % N_SCANS].data_ptr(), n_q, 32))
+                        engs.slotCollect(i & 1)
+                stream(6)
+                tss = []
+                for _ in range(5):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    stream(args.steps)
+                    torch.cuda.synchronize()
+                    tss.append((time.perf_counter() - t1) / args.steps)
+                early["ms_per_scan_pipelined" + ("_early_exit" if ee else "")] = round(1e3 * float(np.median(tss)), 4)
+                engs.close()
+        # ---- several scans against the same map in one graph (BASELINE config 4 on one GPU): the slots' loops advance in
+        # lockstep, one launch per iteration for all of them; scan preparation of all slots in shared launches ------------
         batch_out = []
-        if args.batch:
+        if not args.no_batch:
             p_more = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
-            eng.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
-            for B in (2, 4, 8):
-                def bstep():
-                    for b in range(B):
-                        eng.batchSetScan(b, device_ptr=(d_scans[b].data_ptr(), int(d_scans[b].shape[0]), 32))
-                    eng.batchLaunch(p_more[:B])
-                    return eng.batchCollect()
-                for _ in range(2):
-                    bstep()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(10):
-                    _, bres = bstep()
-                torch.cuda.synchronize()
-                tb = (time.perf_counter() - t1) / 10
-                batch_out.append({"scans_in_flight": B, "ms_per_batch": round(1e3 * tb, 4),
-                                  "lm_iterations_per_s": round(sum(x.iters_run for x in bres) / tb, 1)})
+            for ee, engb in ((0, eng), (1, e2)):
+                engb.setInputCloudDevice(d_map.data_ptr(), n_m, 32)
+                for B in (2, 4, 8):
+                    def bstep():
+                        engb.batchSetScans(device_ptrs=[(d_scans[b].data_ptr(), int(d_scans[b].shape[0]), 32) for b in range(B)])
+                        engb.batchLaunch(p_more[:B])
+                        return engb.batchCollect()
+                    for _ in range(3):
+                        bstep()
+                    tbs = []
+                    for _ in range(5):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        for _ in range(10):
+                            _, bres = bstep()
+                        torch.cuda.synchronize()
+                        tbs.append((time.perf_counter() - t1) / 10)
+                    tb = float(np.median(tbs))
+                    batch_out.append({"scans_in_flight": B, "early_exit": ee, "ms_per_batch": round(1e3 * tb, 4), "ms_per_scan": round(1e3 * tb / B, 4),
+                                      "scans_per_s": round(B / tb, 1), "lm_iterations_per_s": round(sum(x.iters_run for x in bres) / tb, 1)})
         early["batch_one_gpu"] = batch_out
         e2.close()
 
