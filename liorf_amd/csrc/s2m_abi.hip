@@ -105,13 +105,16 @@ struct s2m_context {
     int  seg_iters = 8;                // with early exit on, the loop is issued as launches 0..seg-1 and, only if those did not converge, the rest (env S2M_SEGMENT, 0 = one piece)
     bool seg_pending = false;          // the launch in flight was the first range only
     hipEvent_t ev_a2 = nullptr, ev_b2 = nullptr;
-    int  split_mode = -1;              // env S2M_SPLIT: 1 = every loop runs certify + search kernels, 0 = every loop the fused kernel, default: split for the
-                                       // scan slots of a batch and for 16-wave workgroups (large scans), fused for a single small scan
+    int  split_mode = -1;              // env S2M_SPLIT: 1 = every loop runs certify + search kernels, 0 = every loop the fused kernel, 2 (and the default)
+                                       // = a lockstep batch whose iterations are closed by k_finalize runs the fused kernel up to launch split_from
+                                       // and k_certify_lean + the search kernel from there on; everything else the fused kernel
     bool tune_env = false;             // S2M_TUNE given: the thresholds below are not derived from the workgroup shape
-    int  lean_epw = 2;                 // env S2M_LEAN_EPW=1: one entry per wave in the lean certify kernel (A/B measurements)
+    int  lean_epw = 1;                 // env S2M_LEAN_EPW=2: two entries per wave in the lean certify kernel, four waves per row (A/B measurements: slower)
     bool lean_certify = true;          // env S2M_LEAN=0: the certify role by the general kernel even where the 64-register one applies
     int  batch_entries = 1;            // env S2M_BATCH_ENTRIES: wave-table entries per wave in the scan slots of a batch (fewer, longer-running workgroups)
     int  batch_minw = 4;               // env S2M_BATCH_MINW=4: the search / fused kernel of batch slots in the 128-register build
+    int  search_grid = 8;              // env S2M_SEARCH_GRID: workgroups per slot of a late search launch
+    int  split_from = 8;               // env S2M_SPLIT_FROM: first launch that runs certify + search under S2M_SPLIT=2
     bool lockstep = true;              // env S2M_LOCKSTEP=0: the scans of a batch as parallel branches of the graph instead of one grid row each (A/B measurements)
     bool big_blocks = true;            // env S2M_BIG_BLOCKS=0: 8-wave workgroups whatever the scan size (A/B measurements)
     int density_raw = 320;             // box points above which a wave asks for a finer cut (env S2M_DENSITY_RAW, 0 = off)
@@ -502,6 +505,7 @@ struct LoopShape {
     int wpb = kBlock / 64;  // waves per workgroup (DevCtx::wpb, the same for every slot)
     bool batch = false;     // scan slots of a batch
     bool split = false;     // C + S per iteration instead of R
+    bool late = false;      // the split iterations of this loop come late (few rows on the worklist): small search grid
     bool split_auto = false; // split if the loop's iterations are closed by k_finalize and the lean certify kernel applies
 };
 
@@ -518,9 +522,10 @@ LoopShape shape_of(s2m_context* h)
 }
 
 template <bool HOOK, int NW, int MINW, int MODE, int CNW>
-inline void launch_k(hipStream_t s, const LoopShape& sh, int L, int flags)
+inline void launch_k(hipStream_t s, const LoopShape& sh, int L, int flags, int grid_x = 0)
 {
-    hipLaunchKernelGGL((k_register<HOOK, NW, MINW, MODE, CNW>), dim3(sh.nblocks, sh.nslots), dim3(NW * 64), 0, s, sh.tbl, L, flags);
+    hipLaunchKernelGGL((k_register<HOOK, NW, MINW, MODE, CNW>), dim3(grid_x > 0 ? std::min(grid_x, sh.nblocks) : sh.nblocks, sh.nslots), dim3(NW * 64), 0, s,
+                       sh.tbl, L, flags);
 }
 
 // one fused launch R(L) in the workgroup shape of the scan (DevCtx::wpb); `hook`: the observation variant
@@ -540,13 +545,15 @@ inline void launch_fused(s2m_context* h, const LoopShape& sh, bool hook, int L, 
 }
 
 // the search kernel S(L): over the worklist C(L) left, or (all) over every workgroup
-inline void launch_search(s2m_context* h, const LoopShape& sh, int L, bool all)
+// (small_grid: late in a loop the list is short - a few workgroups per slot walk it instead of one workgroup per row)
+inline void launch_search(s2m_context* h, const LoopShape& sh, int L, bool all, bool small_grid = false)
 {
     constexpr int NW = kBlock / 64;
     const int fl = all ? kFlagAll : 0;
-    if (sh.wpb == kBigWaves) launch_k<false, NW, 2, kSearch, kBigWaves>(h->stream, sh, L, fl);
-    else if (sh.batch && h->batch_minw == 4) launch_k<false, NW, 4, kSearch, NW>(h->stream, sh, L, fl);
-    else                     launch_k<false, NW, 2, kSearch, NW>(h->stream, sh, L, fl);
+    const int gx = (small_grid && !all) ? h->search_grid : 0;
+    if (sh.wpb == kBigWaves) launch_k<false, NW, 2, kSearch, kBigWaves>(h->stream, sh, L, fl, gx);
+    else if (sh.batch && h->batch_minw == 4) launch_k<false, NW, 4, kSearch, NW>(h->stream, sh, L, fl, gx);
+    else                     launch_k<false, NW, 2, kSearch, NW>(h->stream, sh, L, fl, gx);
 }
 
 inline void launch_certify(s2m_context* h, const LoopShape& sh, int L, int solve_prev, bool fused_loop)
@@ -568,7 +575,7 @@ inline void launch_iteration(s2m_context* h, const LoopShape& sh, int L, int sol
     if (!sh.split) { launch_fused(h, sh, false, L, solve_prev); return; }
     if (L == 0) { launch_search(h, sh, 0, true); return; }
     launch_certify(h, sh, L, solve_prev, fused_loop);
-    launch_search(h, sh, L, false);
+    launch_search(h, sh, L, false, sh.late);
 }
 
 inline void launch_finalize(s2m_context* h, const LoopShape& sh, int L, int mode)
@@ -596,12 +603,16 @@ void enqueue_loop(s2m_context* h, const LoopShape& sh_in, hipEvent_t* events, bo
     if (L1 < 0) L1 = n;
     const bool fuse = h->fuse_solve && sh_in.nblocks * sh_in.nslots <= h->fuse_max_blocks;     // the whole grid co-resident (see above)
     LoopShape sh = sh_in;
-    if (sh.split_auto && !fuse && sh.wpb == kBlock / 64 && h->lean_certify) sh.split = true;
+    // S2M_SPLIT=2: from launch `split_from` on (the first launches search most points: there the certify kernel is only one
+    // more launch in front of the search) the iterations of a loop closed by k_finalize run certify (lean) + search
+    const bool split_late = sh.split_auto && !fuse && sh.wpb == kBlock / 64 && h->lean_certify && !h->prm.early_exit;   // (a loop that breaks early never gets there)
     if (h->density_raw > 0 && L0 == 0) launch_density(h, sh);
     for (int L = L0; L < L1; L++) {
         const int slot = !coarse ? 2 * L : (L == 0 ? 0 : (L == 1 ? 2 : (L == n - 1 ? 6 : 4)));
         const bool open = events && (!coarse || L <= 2 || L == n - 1), close = events && (!coarse || L <= 1 || L >= n - 2);
         if (open) (void)hipEventRecord(events[slot], h->stream);
+        sh.split = sh_in.split || (split_late && L >= h->split_from);
+        sh.late = !sh_in.split && sh.split;
         launch_iteration(h, sh, L, (fuse && L >= 2 && L != L0) ? 1 : 0, fuse);
         if (close) (void)hipEventRecord(events[slot + 1], h->stream);
         if (!fuse || L == 0 || L == L1 - 1) launch_finalize(h, sh, L, 0);
@@ -800,6 +811,8 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_SEGMENT")) h->seg_iters = atoi(e);
     if (const char* e = getenv("S2M_SPLIT")) h->split_mode = atoi(e);
     if (const char* e = getenv("S2M_LOCKSTEP")) h->lockstep = !(e[0] == '0');
+    if (const char* e = getenv("S2M_SPLIT_FROM")) h->split_from = std::max(1, atoi(e));
+    if (const char* e = getenv("S2M_SEARCH_GRID")) h->search_grid = std::max(1, atoi(e));
     if (const char* e = getenv("S2M_BATCH_MINW")) h->batch_minw = atoi(e);
     if (const char* e = getenv("S2M_BATCH_ENTRIES")) h->batch_entries = atoi(e);
     if (const char* e = getenv("S2M_LEAN")) h->lean_certify = !(e[0] == '0');
@@ -1124,7 +1137,7 @@ int get_batch_graph(s2m_context* h, const std::vector<int>& live, hipGraphExec_t
                 sh.table_cap = std::max(sh.table_cap, k->hctx.table_cap);
             }
             sh.split = h->split_mode == 1;         // (default: decided in enqueue_loop - split where the loop is not fused)
-            sh.split_auto = h->split_mode == 2;    // (S2M_SPLIT=2: certify + search where the loop is not fused; measured no faster than the fused kernel in lockstep)
+            sh.split_auto = h->split_mode == 2 || h->split_mode < 0;   // (default: certify (lean) + search from launch split_from on, where k_finalize closes the iterations)
             if (sh.nslots) loops.push_back(sh);
         }
     } else

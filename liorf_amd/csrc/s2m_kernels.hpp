@@ -1383,6 +1383,8 @@ __global__ __launch_bounds__(kFinThreads) void k_finalize(const SlotTable tbl, i
     if (mode == 0 && done0) return;
     __shared__ LmShared sh;
     __shared__ float s_out[8];
+    // the worklists of the search kernel start empty behind every close of its own (the certify kernel of the next launch appends)
+    if (mode == 0 && threadIdx.x == 0 && cp->wl_count) { cp->wl_count[0] = 0; cp->wl_count[1] = 0; }
     float pose[6];
     const bool ended = lm_close_iteration<kFinThreads, true>(cp, st, nb_act, iter, true, mode == 1, pose0, degen0, sh, s_out, pose);
     // the transform of the new pose, once, for every workgroup of the next registration launch (which would otherwise

@@ -1410,15 +1410,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     const int nblocks = cp->nblocks;
     const int nb_act = min((n_waves + CNW - 1) / CNW, nblocks);            // workgroups the wave table needs
     // ---- which row of the partition this workgroup works on
+    // (the search kernel over a worklist: workgroup j takes items j, j + gridDim.x, ... - late in a loop the list is short or
+    // empty and a small grid costs less to launch than one workgroup per row)
     int b = (int)blockIdx.x;
-    if (MODE == kSearch && !(flags & kFlagAll)) {
+    int wl_cnt = 0, wl_at = (int)blockIdx.x;
+    const bool listed = MODE == kSearch && !(flags & kFlagAll);
+    if (listed) {
         const auto wlc = G(cp->wl_count);
-        const int cnt = wlc[launch & 1];
-        if (b == 0 && tid == 0) { wlc[(launch + 1) & 1] = 0; st->deferred_total += cnt; }   // the next launch's list starts empty (nobody reads or appends to it now)
-        if (b >= cnt) return;
-        b = __builtin_amdgcn_readfirstlane(G(cp->wl_items)[(size_t)(launch & 1) * (size_t)nblocks + b]);
+        wl_cnt = wlc[launch & 1];
+        if (b == 0 && tid == 0) { wlc[(launch + 1) & 1] = 0; st->deferred_total += wl_cnt; }   // the next launch's list starts empty (nobody reads or appends to it now)
     } else if (MODE == kSearch) {
         if (b == 0 && tid == 0) G(cp->wl_count)[(launch + 1) & 1] = 0;
+    }
+    for (;;) {
+    if (listed) {
+        if (wl_at >= wl_cnt) return;
+        b = __builtin_amdgcn_readfirstlane(G(cp->wl_items)[(size_t)(launch & 1) * (size_t)nblocks + wl_at]);
     }
     if (b >= nb_act) return;                                                // the rest of the (fixed, graph-captured) grid idles
     // Wave w of workgroup b starts at entry w*nb_act + b of the wave table and advances by the number of waves in
@@ -1730,4 +1737,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     } else
         __syncthreads();
     write_partial_row<CNW>(cp, launch, b, tid, red);
+    if (!listed) return;
+    wl_at += (int)gridDim.x;
+    __syncthreads();                                      // (the next item reuses the workgroup's LDS)
+    }
 }
