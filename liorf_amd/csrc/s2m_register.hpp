@@ -479,7 +479,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             // a dense box under a wide pass: both sweeps cost lanes x tile points - half the lanes see a smaller box, and the
             // other half of the wave shares their sweeps
             // (lanes with a tuple to start from count against tight radii and list few candidates: measured, the cut does not pay there)
-            if (__ballot(act && has_prior) == 0ull &&
+            if (__ballot(act && (cp->tune[2] ? tight : has_prior)) == 0ull &&
                 ((nA > 32 && ptot > cp->tune[0]) || (nA > 16 && nA <= 32 && ptot > cp->tune[1]))) { tile = false; if (HOOK) prof.why = 4; break; }
             // ---- stage through the filter: 16 lanes per row, 8 rows in flight per pass; a point
             // enters the tile only if it lies inside the lanes' point box grown by the largest radius.
