@@ -113,6 +113,7 @@ struct s2m_context {
     bool lean_certify = true;          // env S2M_LEAN=0: the certify role by the general kernel even where the 64-register one applies
     int  batch_entries = 1;            // env S2M_BATCH_ENTRIES: wave-table entries per wave in the scan slots of a batch (fewer, longer-running workgroups)
     int  batch_minw = 4;               // env S2M_BATCH_MINW=4: the search / fused kernel of batch slots in the 128-register build
+    bool close_in_search = true;       // env S2M_CLOSE_IN_SEARCH=0: late split iterations keep a k_finalize launch of their own
     int  search_grid = 8;              // env S2M_SEARCH_GRID: workgroups per slot of a late search launch
     int  split_from = 8;               // env S2M_SPLIT_FROM: first launch that runs certify + search under S2M_SPLIT=2
     bool lockstep = true;              // env S2M_LOCKSTEP=0: the scans of a batch as parallel branches of the graph instead of one grid row each (A/B measurements)
@@ -549,8 +550,9 @@ inline void launch_fused(s2m_context* h, const LoopShape& sh, bool hook, int L, 
 inline void launch_search(s2m_context* h, const LoopShape& sh, int L, bool all, bool small_grid = false)
 {
     constexpr int NW = kBlock / 64;
-    const int fl = all ? kFlagAll : 0;
-    const int gx = (small_grid && !all) ? h->search_grid : 0;
+    const bool close_after = small_grid && !all && h->close_in_search;     // one workgroup per slot walks the list and closes the iteration
+    const int fl = (all ? kFlagAll : 0) | (close_after ? kFlagCloseAfter : 0);
+    const int gx = close_after ? 1 : ((small_grid && !all) ? h->search_grid : 0);
     if (sh.wpb == kBigWaves) launch_k<false, NW, 2, kSearch, kBigWaves>(h->stream, sh, L, fl, gx);
     else if (sh.batch && h->batch_minw == 4) launch_k<false, NW, 4, kSearch, NW>(h->stream, sh, L, fl, gx);
     else                     launch_k<false, NW, 2, kSearch, NW>(h->stream, sh, L, fl, gx);
@@ -615,7 +617,7 @@ void enqueue_loop(s2m_context* h, const LoopShape& sh_in, hipEvent_t* events, bo
         sh.late = !sh_in.split && sh.split;
         launch_iteration(h, sh, L, (fuse && L >= 2 && L != L0) ? 1 : 0, fuse);
         if (close) (void)hipEventRecord(events[slot + 1], h->stream);
-        if (!fuse || L == 0 || L == L1 - 1) launch_finalize(h, sh, L, 0);
+        if ((!fuse || L == 0 || L == L1 - 1) && !(sh.late && h->close_in_search)) launch_finalize(h, sh, L, 0);   // (late split: the search launch closes)
     }
 }
 
@@ -813,6 +815,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_LOCKSTEP")) h->lockstep = !(e[0] == '0');
     if (const char* e = getenv("S2M_SPLIT_FROM")) h->split_from = std::max(1, atoi(e));
     if (const char* e = getenv("S2M_SEARCH_GRID")) h->search_grid = std::max(1, atoi(e));
+    if (const char* e = getenv("S2M_CLOSE_IN_SEARCH")) h->close_in_search = !(e[0] == '0');
     if (const char* e = getenv("S2M_BATCH_MINW")) h->batch_minw = atoi(e);
     if (const char* e = getenv("S2M_BATCH_ENTRIES")) h->batch_entries = atoi(e);
     if (const char* e = getenv("S2M_LEAN")) h->lean_certify = !(e[0] == '0');

@@ -1081,6 +1081,7 @@ constexpr int kCertifyLeanWaves = 8;   // the lean certify kernel: 64 registers
 constexpr int kCertifyLeanEpw = 2;     // ... two entries per wave: four waves write a row of eight    // ... and in the 16-wave shape of large scans
 constexpr int kFlagSolvePrev = 1;      // the prologue closes iteration launch-1 (fused loop)
 constexpr int kFlagAll = 2;            // kSearch: every workgroup, no worklist (launch 0 of a scan, observation hooks)
+constexpr int kFlagCloseAfter = 4;     // kSearch on a grid of ONE workgroup per slot: walk the whole worklist, then close this iteration (k_finalize's job) right here
 // ---- wave reduction by recursive halving, 16 sums at a time: at mask m a lane keeps one half of its sums and hands the
 // other half to lane^m, so 8+4+2+1 values cross instead of 4 x 16; after the four steps lane l holds, in a[0], sum number
 // l>>2 over the 16 lanes that share its two low bits, and two full exchanges complete it.  Fixed order: bitwise
@@ -1424,7 +1425,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     }
     for (;;) {
     if (listed) {
-        if (wl_at >= wl_cnt) return;
+        if (wl_at >= wl_cnt) {
+            if (!(flags & kFlagCloseAfter)) return;
+            break;                                                          // the list is done: close the iteration below
+        }
         b = __builtin_amdgcn_readfirstlane(G(cp->wl_items)[(size_t)(launch & 1) * (size_t)nblocks + wl_at]);
     }
     if (b >= nb_act) return;                                                // the rest of the (fixed, graph-captured) grid idles
@@ -1740,5 +1744,29 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     if (!listed) return;
     wl_at += (int)gridDim.x;
     __syncthreads();                                      // (the next item reuses the workgroup's LDS)
+    }
+    // ---- kFlagCloseAfter: this workgroup is the only one of its slot in this launch and every row of the iteration is written
+    // (by the certify kernel before this launch, or above): what k_finalize would do in a launch of its own
+    if (MODE == kSearch) {
+        __syncthreads();
+        LmShared& sh = *reinterpret_cast<LmShared*>(&s_pts[0][0]);
+        static_assert(MODE != kSearch || sizeof(LmShared) <= sizeof(v4f) * kTilePts * NW, "LM scratch must fit the tile area");
+        float pose0[6], pose[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) pose0[k] = st->pose2[launch & 1][k];
+        const int degen0 = st->isDegenerate;
+        if (tid == 0) { cp->wl_count[0] = 0; cp->wl_count[1] = 0; }
+        const bool ended = lm_close_iteration<NW * 64, false>(cp, st, nb_act, launch, true, false, pose0, degen0, sh, s_lm_out, pose);
+        if (!ended && tid < 64) {
+            float Tn[12], scn[6];
+            build_transform(pose, tid, Tn, scn);
+            if (tid == 0 && !st->stalled) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) st->T[k] = Tn[k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) st->sc[k] = scn[k];
+                st->T_valid = 1;
+            }
+        }
     }
 }
