@@ -113,7 +113,9 @@ struct s2m_context {
     bool lean_certify = true;          // env S2M_LEAN=0: the certify role by the general kernel even where the 64-register one applies
     int  batch_entries = 1;            // env S2M_BATCH_ENTRIES: wave-table entries per wave in the scan slots of a batch (fewer, longer-running workgroups)
     int  batch_minw = 4;               // env S2M_BATCH_MINW=4: the search / fused kernel of batch slots in the 128-register build
-    bool close_in_search = true;       // env S2M_CLOSE_IN_SEARCH=0: late split iterations keep a k_finalize launch of their own
+    bool close_in_search = false;      // env S2M_CLOSE_IN_SEARCH=1: late split iterations without a k_finalize launch - ONE search workgroup per slot walks the
+                                       // worklist and closes the iteration (1 % faster on the benchmark batch, but a slot with several deferred workgroups then
+                                       // works them off one after the other: 70 us in a launch that had three)
     int  search_grid = 8;              // env S2M_SEARCH_GRID: workgroups per slot of a late search launch
     int  split_from = 8;               // env S2M_SPLIT_FROM: first launch that runs certify + search under S2M_SPLIT=2
     bool lockstep = true;              // env S2M_LOCKSTEP=0: the scans of a batch as parallel branches of the graph instead of one grid row each (A/B measurements)
@@ -815,7 +817,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_LOCKSTEP")) h->lockstep = !(e[0] == '0');
     if (const char* e = getenv("S2M_SPLIT_FROM")) h->split_from = std::max(1, atoi(e));
     if (const char* e = getenv("S2M_SEARCH_GRID")) h->search_grid = std::max(1, atoi(e));
-    if (const char* e = getenv("S2M_CLOSE_IN_SEARCH")) h->close_in_search = !(e[0] == '0');
+    if (const char* e = getenv("S2M_CLOSE_IN_SEARCH")) h->close_in_search = (e[0] == '1');
     if (const char* e = getenv("S2M_BATCH_MINW")) h->batch_minw = atoi(e);
     if (const char* e = getenv("S2M_BATCH_ENTRIES")) h->batch_entries = atoi(e);
     if (const char* e = getenv("S2M_LEAN")) h->lean_certify = !(e[0] == '0');
