@@ -1204,8 +1204,13 @@ int s2m_batch_set_scans(s2m_handle h, int n_scans, const void* const* scans, con
         const int nb = std::min(kPrepSlots, n_scans - b0);
         for (int j = 0; j < nb; j++) {
             s2m_context* k = h->kids[(size_t)(b0 + j)];
-            if ((rc = adopt_map(h, k))) return fail(h, rc, k->err.c_str());
-            if ((rc = scan_slot_prepare(k, scans[b0 + j], sizes[b0 + j], stride_bytes, on_device != 0, &t.s[j]))) return fail(h, rc, k->err.c_str());
+            if ((rc = adopt_map(h, k)) == S2M_OK) rc = scan_slot_prepare(k, scans[b0 + j], sizes[b0 + j], stride_bytes, on_device != 0, &t.s[j]);
+            if (rc) {
+                // the slots prepared so far in this group have not been ordered: none of them holds a scan
+                for (int q = 0; q <= j; q++) h->kids[(size_t)(b0 + q)]->have_scan = false;
+                (void)hipStreamSynchronize(h->stream);
+                return fail(h, rc, k->err.c_str());
+            }
             k->t_set_scan_ms = 0; k->scan_timing_pending = false;
         }
         launch_scan_prep(h->stream, t, nb);

@@ -143,3 +143,25 @@ def test_stream_of_scans_through_two_slots_equals_separate_calls_bitwise():
             tr = np.array([t.pose[:] for t in gpu.batchTrace(i & 1)], np.float32)
             assert tr.shape == solo[i][3].shape and np.array_equal(tr.view(np.uint32), solo[i][3].view(np.uint32)), (early, i)
         gpu.close()
+
+
+def test_batched_set_scans_rejects_a_bad_slot_and_recovers(cfg_small):
+    """s2m_batch_set_scans with an invalid record stride in the middle of the batch: an error, no slot of the call holds a
+    scan afterwards (a launch is refused), and the same handle then takes a good batch and gives the solo results."""
+    import ctypes as C
+    m, s0 = synth.to_xyzi(cfg_small["map"]), synth.to_xyzi(cfg_small["scan"])
+    gpu = s2m.MapOptimizationS2M()
+    gpu.setInputCloud(m)
+    n = 3
+    ptrs = (C.c_void_p * n)(*[C.c_void_p(s0.ctypes.data)] * n)
+    sizes = (C.c_size_t * n)(len(s0), len(s0), len(s0))
+    rc = gpu.lib.s2m_batch_set_scans(gpu.h, n, ptrs, sizes, 6, 0)           # stride 6: not a record
+    assert rc != 0
+    poses = np.stack([cfg_small["pose_init"]] * n).astype(np.float32)
+    with pytest.raises(s2m.S2MError):
+        gpu.batchLaunch(poses)
+    out, res = gpu.optimizeBatch([s0] * n, poses)
+    solo = _solo(m, s0, cfg_small["pose_init"])
+    for b in range(n):
+        assert np.array_equal(out[b].view(np.uint32), solo[0].view(np.uint32))
+    gpu.close()
