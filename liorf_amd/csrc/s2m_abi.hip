@@ -109,7 +109,6 @@ struct s2m_context {
                                        // = a lockstep batch whose iterations are closed by k_finalize runs the fused kernel up to launch split_from
                                        // and k_certify_lean + the search kernel from there on; everything else the fused kernel
     bool tune_env = false;             // S2M_TUNE given: the thresholds below are not derived from the workgroup shape
-    int  lean_epw = 1;                 // env S2M_LEAN_EPW=2: two entries per wave in the lean certify kernel, four waves per row (A/B measurements: slower)
     bool lean_certify = true;          // env S2M_LEAN=0: the certify role by the general kernel even where the 64-register one applies
     int  batch_entries = 1;            // env S2M_BATCH_ENTRIES: wave-table entries per wave in the scan slots of a batch (fewer, longer-running workgroups)
     int  batch_minw = 4;               // env S2M_BATCH_MINW=4: the search / fused kernel of batch slots in the 128-register build
@@ -565,10 +564,7 @@ inline void launch_certify(s2m_context* h, const LoopShape& sh, int L, int solve
     constexpr int NW = kBlock / 64;
     const int fl = solve_prev ? kFlagSolvePrev : 0;
     if (!fused_loop && sh.wpb == NW && h->lean_certify)      // iterations closed by k_finalize: the 64-register kernel
-    {
-        if (h->lean_epw == 1) hipLaunchKernelGGL((k_certify_lean<NW, 1, kCertifyLeanWaves>), dim3(sh.nblocks, sh.nslots), dim3(NW * 64), 0, h->stream, sh.tbl, L);
-        else hipLaunchKernelGGL((k_certify_lean<NW, kCertifyLeanEpw, kCertifyLeanWaves>), dim3(sh.nblocks, sh.nslots), dim3(NW / kCertifyLeanEpw * 64), 0, h->stream, sh.tbl, L);
-    }
+        hipLaunchKernelGGL((k_certify_lean<NW, 1, kCertifyLeanWaves>), dim3(sh.nblocks, sh.nslots), dim3(NW * 64), 0, h->stream, sh.tbl, L);
     else if (sh.wpb == kBigWaves) launch_k<false, kBigWaves, kCertifyWavesBig, kCertify, kBigWaves>(h->stream, sh, L, fl);
     else                     launch_k<false, NW, kCertifyWaves, kCertify, NW>(h->stream, sh, L, fl);
 }
@@ -821,7 +817,6 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (const char* e = getenv("S2M_BATCH_MINW")) h->batch_minw = atoi(e);
     if (const char* e = getenv("S2M_BATCH_ENTRIES")) h->batch_entries = atoi(e);
     if (const char* e = getenv("S2M_LEAN")) h->lean_certify = !(e[0] == '0');
-    if (const char* e = getenv("S2M_LEAN_EPW")) h->lean_epw = atoi(e);
     h->fuse_max_blocks = kFuseMaxBlocks;
     if (const char* e = getenv("S2M_FUSE_MAX")) h->fuse_max_blocks = atoi(e);
 
@@ -871,6 +866,7 @@ int s2m_destroy(s2m_handle h)
     if (!h) return S2M_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipStream_t st : h->branch_streams) (void)hipStreamSynchronize(st);      // (slot work in flight uses the slots' buffers)
     for (s2m_context* k : h->kids) (void)s2m_destroy(k);
     h->kids.clear();
     if (h->kid_states.p) (void)hipFree(h->kid_states.p);

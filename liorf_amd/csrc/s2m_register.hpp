@@ -1197,7 +1197,9 @@ __device__ __forceinline__ bool lane_needs(const float (&T)[12], float px, float
 // does not settle - and any partition with more than one entry per wave - sends the workgroup to the search kernel.
 // ------------------------------------------------------------------------------------------
 // (EPW entries per wave: a workgroup of NW / EPW waves writes the row of NW entries - every entry reduced on its own, the
-// row summed in entry order, exactly as a workgroup of NW waves would - so that twice as many rows are in flight per CU.)
+// row summed in entry order, exactly as a workgroup of NW waves would - so that twice as many rows are in flight per CU.
+// Only EPW = 1 is instantiated: EPW = 2 was measured slower - the rolled loop over the entries costs more instructions than
+// the second round of workgroups costs time - and needed 24 bytes of scratch.)
 template <int NW, int EPW, int MINW>
 __global__ __launch_bounds__(NW / EPW * 64, MINW) void k_certify_lean(const SlotTable tbl, int launch)
 {

@@ -165,3 +165,27 @@ def test_batched_set_scans_rejects_a_bad_slot_and_recovers(cfg_small):
     for b in range(n):
         assert np.array_equal(out[b].view(np.uint32), solo[0].view(np.uint32))
     gpu.close()
+
+
+def test_batch_of_eight_kitti64_scans_all_thirty_iterations():
+    """The benchmark's batch: 8 kitti64 scans, early exit off.  The lockstep loop runs the fused kernel for launches 0-7 and
+    k_certify_lean + the search kernel + k_finalize from launch 8 on (the default for a batch whose grid is too large for the
+    fused close); every slot's trace - 30 poses - must be bitwise the trace of a separate call, and the search kernel must have
+    had next to nothing to do in the late launches."""
+    cfgs = [synth.make_config("kitti64", scan_index=k) for k in range(8)]
+    m = synth.to_xyzi(cfgs[0]["map"])
+    scans = [synth.to_xyzi(c["scan"]) for c in cfgs]
+    poses = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
+    gpu = s2m.MapOptimizationS2M(early_exit=0)
+    gpu.setInputCloud(m)
+    for rep in range(2):
+        out, res = gpu.optimizeBatch(scans, poses)
+        for b in (0, 2, 5, 7):
+            want = _solo(m, scans[b], poses[b], early_exit=0)
+            assert res[b].iters_run == 30 and want[1][0] == 30
+            assert np.array_equal(out[b].view(np.uint32), want[0].view(np.uint32)), b
+            tr = np.array([t.pose[:] for t in gpu.batchTrace(b)], np.float32)
+            assert tr.shape == want[3].shape and np.array_equal(tr.view(np.uint32), want[3].view(np.uint32)), b
+        deferred = [int(gpu.lib.s2m_debug_deferred(gpu.h, b)) for b in range(8)]
+        assert max(deferred) <= 64, deferred            # (255 workgroups x 22 launches per scan were candidates)
+    gpu.close()

@@ -230,9 +230,9 @@ def test_lockstep_batch_with_the_lean_certify_kernel_equals_separate_calls_bitwi
         r = g.optimize(s_, p_)
         solo.append((np.array(r.pose, np.float32), r.iters_run, np.array([t.pose[:] for t in g.trace()], np.float32)))
         g.close()
-    for env in ({"S2M_SPLIT": "2", "S2M_FUSE_MAX": "0"}, {"S2M_SPLIT": "2", "S2M_FUSE_MAX": "0", "S2M_LEAN_EPW": "1"},
+    for env in ({"S2M_SPLIT": "2", "S2M_FUSE_MAX": "0"},
                 {"S2M_SPLIT": "0", "S2M_LOCKSTEP": "0"}, {"S2M_SPLIT": "1"}):
-        for k in ("S2M_SPLIT", "S2M_FUSE_MAX", "S2M_LEAN_EPW", "S2M_LOCKSTEP"):
+        for k in ("S2M_SPLIT", "S2M_FUSE_MAX", "S2M_LOCKSTEP"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
