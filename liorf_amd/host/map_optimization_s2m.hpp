@@ -176,6 +176,54 @@ public:
         }
     }
 
+    // No counterpart in the reference (it registers one scan at a time under `mtx`, :252): n scans against the resident map at
+    // once - s2m_optimize_batch, the scans' LM loops in lockstep inside one graph.  `scans[b]` = laserCloudSurfLastDS of scan b,
+    // `poses[6*b..]` in: initial guess, out: transformTobeMapped of scan b; results as lastResult would hold them.  Bitwise
+    // what n calls of scan2MapOptimization() give.
+    std::vector<s2m_result> scan2MapOptimizationBatch(const std::vector<const std::vector<PointXYZI>*>& scans, std::vector<float>& poses,
+                                                      const std::vector<CloudInfo>* infos = nullptr)
+    {
+        pushParams();
+        const int n = (int)scans.size();
+        if ((int)poses.size() != 6 * n) throw std::runtime_error("scan2MapOptimizationBatch: poses must hold 6 floats per scan");
+        std::vector<const void*> ptrs((size_t)n);
+        std::vector<size_t> sizes((size_t)n);
+        for (int b = 0; b < n; b++) { ptrs[(size_t)b] = scans[(size_t)b]->data(); sizes[(size_t)b] = scans[(size_t)b]->size(); }
+        std::vector<s2m_imu_init> imu((size_t)n);
+        for (int b = 0; b < n; b++) {
+            const CloudInfo& ci = infos ? (*infos)[(size_t)b] : cloudInfo;
+            imu[(size_t)b].imuAvailable = ci.imuAvailable;
+            imu[(size_t)b].imuRollInit = ci.imuRollInit; imu[(size_t)b].imuPitchInit = ci.imuPitchInit; imu[(size_t)b].imuYawInit = ci.imuYawInit;
+        }
+        std::vector<s2m_result> res((size_t)n);
+        check(s2m_optimize_batch(h_, n, ptrs.data(), sizes.data(), sizeof(PointXYZI), poses.data(), imu.data(), res.data()), "s2m_optimize_batch");
+        return res;
+    }
+
+    // A stream of scans through two slots (s2m_slot_*): prepareNextScan(slot, cloud) orders the NEXT scan on that slot's stream
+    // while the loop launched with launchSlot() on the other slot runs; collectSlot() is scan2MapOptimization()'s second half
+    // (synchronise, transformUpdate(), members updated).  The reference does the steps strictly one after the other (:257-265).
+    void prepareNextScan(int slot, const std::vector<PointXYZI>& cloud)
+    {
+        check(s2m_slot_set_scan(h_, slot, cloud.data(), cloud.size(), sizeof(PointXYZI), 0), "s2m_slot_set_scan");
+    }
+    void launchSlot(int slot)
+    {
+        pushParams();
+        check(s2m_slot_optimize_launch(h_, slot, transformTobeMapped), "s2m_slot_optimize_launch");
+    }
+    void collectSlot(int slot)
+    {
+        s2m_imu_init imu;
+        imu.imuAvailable = cloudInfo.imuAvailable;
+        imu.imuRollInit = cloudInfo.imuRollInit; imu.imuPitchInit = cloudInfo.imuPitchInit; imu.imuYawInit = cloudInfo.imuYawInit;
+        check(s2m_slot_optimize_collect(h_, slot, transformTobeMapped, &imu, &lastResult), "s2m_slot_optimize_collect");
+        if (lastResult.skipped == 0) {
+            isDegenerate = lastResult.is_degenerate != 0;
+            std::memcpy(incrementalOdometryAffineBack, lastResult.affine, sizeof(incrementalOdometryAffineBack));
+        }
+    }
+
     // The ICP block of performRSLoopClosure / performSCLoopClosure (:571-586, :663-678): settings, align(),
     // hasConverged(), getFitnessScore(), getFinalTransformation().  Returns false where the reference returns early.
     float historyKeyframeSearchRadius = 10.0f;        // include/utility.h:245

@@ -108,7 +108,7 @@ public:
     void scan2MapOptimization(bool keyPosesEmpty, int laserCloudSurfLastDSNum, const liorf::cloud_info& cloudInfo, float transformTobeMapped[6],
                               bool& isDegenerate, Eigen::Affine3f& incrementalOdometryAffineBack)
     {
-        if (keyPosesEmpty) return;                                                               // :1297
+        if (keyPosesEmpty || !haveMap_) return;                                                  // :1297 (no key pose yet: no map was extracted)
         s2m_imu_init imu;
         imu.imuAvailable = cloudInfo.imuAvailable;
         imu.imuRollInit = cloudInfo.imuRollInit; imu.imuPitchInit = cloudInfo.imuPitchInit; imu.imuYawInit = cloudInfo.imuYawInit;

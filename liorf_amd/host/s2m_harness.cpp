@@ -67,11 +67,53 @@ static int run_chain(char** argv)
     return 0;
 }
 
+// --many map.bin roll pitch yaw x y z scan0.bin scan1.bin ...: the same initial guess for every scan; the scans once as a batch
+// (scan2MapOptimizationBatch), once as a stream through two slots (prepareNextScan / launchSlot / collectSlot), once one by one
+// (scan2MapOptimization): prints "batch|stream|single <i> iters <n> pose ..." - the three must agree bit for bit.
+static int run_many(int argc, char** argv)
+{
+    liorf_amd::MapOptimizationS2M node;
+    node.laserCloudSurfFromMapDS = read_cloud(argv[2]);
+    node.haveKeyPoses = !node.laserCloudSurfFromMapDS.empty();
+    float guess[6];
+    for (int k = 0; k < 6; k++) guess[k] = (float)std::atof(argv[3 + k]);
+    std::vector<std::vector<liorf_amd::PointXYZI>> scans;
+    for (int a = 9; a < argc; a++) scans.push_back(read_cloud(argv[a]));
+    const int n = (int)scans.size();
+    node.setInputCloud();
+    auto show = [](const char* tag, int i, int iters, const float* p) {
+        std::printf("%s %d iters %d pose %.9g %.9g %.9g %.9g %.9g %.9g\n", tag, i, iters, p[0], p[1], p[2], p[3], p[4], p[5]);
+    };
+    {
+        std::vector<const std::vector<liorf_amd::PointXYZI>*> ptrs;
+        std::vector<float> poses;
+        for (int b = 0; b < n; b++) { ptrs.push_back(&scans[(size_t)b]); for (int k = 0; k < 6; k++) poses.push_back(guess[k]); }
+        const std::vector<s2m_result> res = node.scan2MapOptimizationBatch(ptrs, poses);
+        for (int b = 0; b < n; b++) show("batch", b, res[(size_t)b].iters_run, &poses[(size_t)6 * (size_t)b]);
+    }
+    node.prepareNextScan(0, scans[0]);
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 6; k++) node.transformTobeMapped[k] = guess[k];
+        node.launchSlot(i & 1);
+        if (i + 1 < n) node.prepareNextScan((i + 1) & 1, scans[(size_t)i + 1]);
+        node.collectSlot(i & 1);
+        show("stream", i, node.lastResult.iters_run, node.transformTobeMapped);
+    }
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 6; k++) node.transformTobeMapped[k] = guess[k];
+        node.laserCloudSurfLastDS = scans[(size_t)i];
+        node.scan2MapOptimization();
+        show("single", i, node.lastResult.iters_run, node.transformTobeMapped);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     try {
         if (argc == 2 && std::string(argv[1]) == "--version") { std::puts(s2m_version()); return 0; }
         if (argc == 13 && std::string(argv[1]) == "--chain") return run_chain(argv);
+        if (argc >= 10 && std::string(argv[1]) == "--many") return run_many(argc, argv);
         if (argc != 9 && argc != 16) {
             std::fprintf(stderr, "usage: %s map.bin scan.bin roll pitch yaw x y z [imuType imuRPYWeight z_tol rot_tol imuAvailable imuRoll imuPitch]\n", argv[0]);
             return 2;

@@ -189,3 +189,30 @@ def test_batch_of_eight_kitti64_scans_all_thirty_iterations():
         deferred = [int(gpu.lib.s2m_debug_deferred(gpu.h, b)) for b in range(8)]
         assert max(deferred) <= 64, deferred            # (255 workgroups x 22 launches per scan were candidates)
     gpu.close()
+
+
+def test_cpp_mirror_batch_and_stream_methods_agree_with_single_calls(tmp_path):
+    """liorf_amd/host/map_optimization_s2m.hpp: scan2MapOptimizationBatch and prepareNextScan / launchSlot / collectSlot give,
+    scan for scan, the very bits of scan2MapOptimization (s2m_harness --many)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "liorf_amd", "host", "s2m_harness")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "liorf_amd", "host")])
+    cfgs = [synth.make_config("small", scan_index=k) for k in range(4)]
+    (tmp_path / "m.bin").write_bytes(synth.to_xyzi(cfgs[0]["map"]).tobytes())
+    files = []
+    for k, c in enumerate(cfgs):
+        (tmp_path / f"s{k}.bin").write_bytes(synth.to_xyzi(c["scan"]).tobytes())
+        files.append(str(tmp_path / f"s{k}.bin"))
+    out = subprocess.run([exe, "--many", str(tmp_path / "m.bin")] + ["%.9g" % v for v in cfgs[0]["pose_init"]] + files,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = {}
+    for l in out.stdout.splitlines():
+        p = l.split()
+        rows.setdefault(p[0], {})[int(p[1])] = p[2:]
+    assert set(rows) == {"batch", "stream", "single"} and all(len(rows[k]) == 4 for k in rows)
+    for i in range(4):
+        assert rows["batch"][i] == rows["single"][i] == rows["stream"][i], (i, rows["batch"][i], rows["stream"][i], rows["single"][i])
+        assert int(rows["single"][i][1]) > 1
