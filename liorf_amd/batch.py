@@ -49,6 +49,51 @@ class RecordGatherer:
             for k, scan in enumerate(shard_scans(n_scans, self.world, r)):
                 self.row_scan[r * self.per_rank + k] = scan
 
+    # ---- the same exchange, split in two so that it runs behind the next registration: gather_begin() enqueues upload,
+    # all-gather and download on a side stream and returns; gather_end() waits for them and returns the table.  At most one
+    # exchange is in flight: a second gather_begin() finishes the first.  (Measured on one MI355X in a world-size-1 nccl group:
+    # the blocking gather() costs 48 us per 0.66 ms step.)
+    def gather_begin(self, local: np.ndarray) -> None:
+        if getattr(self, "_pending", False):
+            self.gather_end()
+        mine = np.asarray(local, np.float32).reshape(-1, RECORD_FLOATS)
+        if mine.shape[0] != len(self.mine):
+            raise ValueError("record count does not match this rank's shard")
+        self.h_send.fill_(float("nan"))
+        if mine.shape[0]:
+            self.h_send[: mine.shape[0]] = torch.from_numpy(mine)
+        if not self.d_send.is_cuda:
+            self._table = self.gather(mine)                # CPU group (gloo): nothing to overlap with
+            self._pending = True
+            return
+        if not hasattr(self, "_stream"):
+            self._stream = torch.cuda.Stream(device=self.d_send.device)
+            self._event = torch.cuda.Event()
+        with torch.cuda.stream(self._stream):
+            self.d_send.copy_(self.h_send, non_blocking=True)
+            if dist.is_initialized():
+                work = dist.all_gather_into_tensor(self.d_recv, self.d_send, group=self.group, async_op=True)
+                work.wait()                                # orders the side stream behind the collective; does not block the host
+            else:
+                self.d_recv.copy_(self.d_send)
+            self.h_recv.copy_(self.d_recv, non_blocking=True)
+            self._event.record(self._stream)
+        self._table = None
+        self._pending = True
+
+    def gather_end(self) -> np.ndarray:
+        if not getattr(self, "_pending", False):
+            raise RuntimeError("gather_end without gather_begin")
+        self._pending = False
+        if self._table is not None:
+            return self._table
+        self._event.synchronize()
+        rows = self.h_recv.numpy()
+        table = np.full((self.n_scans, RECORD_FLOATS), np.nan, np.float32)
+        ok = self.row_scan[: rows.shape[0]] >= 0
+        table[self.row_scan[: rows.shape[0]][ok]] = rows[ok]
+        return table
+
     def gather(self, local: np.ndarray) -> np.ndarray:
         mine = np.asarray(local, np.float32).reshape(-1, RECORD_FLOATS)
         if mine.shape[0] != len(self.mine):

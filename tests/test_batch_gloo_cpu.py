@@ -30,6 +30,11 @@ def _worker(rank, world, port, n_scans, q):
         recs = np.stack([batch.pack_record([0.01 * s, -0.02 * s, 0.3 + s, 1.5 + s, -0.7, 0.1], 5 + s, 1000 * s)
                          for s in mine]) if mine else np.zeros((0, 8), np.float32)
         table = batch.gather_records(recs, n_scans)
+        # the two-step form bench.py uses (exchange behind the next registration): same table, twice in a row on one object
+        g = batch.RecordGatherer(n_scans)
+        g.gather_begin(recs)
+        g.gather_begin(recs)                      # finishes the first one
+        assert np.array_equal(g.gather_end(), table, equal_nan=True)
         q.put((rank, table))
     finally:
         dist.destroy_process_group()

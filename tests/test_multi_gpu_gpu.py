@@ -141,6 +141,14 @@ def test_record_gatherer_device_branch_under_nccl(cfg_tiny):
         table = gat.h_recv.numpy()
         for k in range(2):
             assert np.array_equal(table[k, :6], want[k]) and table[k, 6] > 0
+        # the two-step form bench.py --gpus N uses: the exchange on a side stream behind the next registration
+        gat.gather_begin(np.stack(recs))
+        r = g.optimize(synth.to_xyzi(scans[0]["scan"]), scans[0]["pose_init"])          # (work of the library's own stream meanwhile)
+        t2 = gat.gather_end()
+        assert np.array_equal(t2, np.stack(recs)) and np.array_equal(np.array(r.pose, np.float32), want[0])
+        gat.gather_begin(np.stack(recs)[::-1].copy())
+        gat.gather_begin(np.stack(recs))                                                 # finishes the one before
+        assert np.array_equal(gat.gather_end(), np.stack(recs))
         full = gat.gather(np.stack(recs))
         assert np.array_equal(full[:, :6], np.stack(want))
         g.close()
