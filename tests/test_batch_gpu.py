@@ -216,3 +216,20 @@ def test_cpp_mirror_batch_and_stream_methods_agree_with_single_calls(tmp_path):
     for i in range(4):
         assert rows["batch"][i] == rows["single"][i] == rows["stream"][i], (i, rows["batch"][i], rows["stream"][i], rows["single"][i])
         assert int(rows["single"][i][1]) > 1
+
+
+def test_batch_with_both_workgroup_shapes():
+    """Slots of different workgroup shape (8-wave and 16-wave) in one batch: two lockstep loops on branches of their own inside
+    the one graph; every slot still gives the bits of a separate call."""
+    cfg = synth.make_config("ouster128")
+    m, s = synth.to_xyzi(cfg["map"]), synth.to_xyzi(cfg["scan"])
+    scans = [s[:20000].copy(), s, s[20000:45000].copy(), s[:200000].copy()]
+    poses = np.stack([cfg["pose_init"]] * len(scans)).astype(np.float32)
+    gpu = s2m.MapOptimizationS2M()
+    gpu.setInputCloud(m)
+    out, res = gpu.optimizeBatch(scans, poses)
+    for b in range(len(scans)):
+        want = _solo(m, scans[b], poses[b])
+        assert (res[b].iters_run, res[b].converged, res[b].n_sel_last) == (want[1][0], want[1][1], want[1][3]), b
+        assert np.array_equal(out[b].view(np.uint32), want[0].view(np.uint32)), b
+    gpu.close()
