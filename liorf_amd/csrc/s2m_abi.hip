@@ -1195,6 +1195,13 @@ int s2m_batch_set_scans(s2m_handle h, int n_scans, const void* const* scans, con
     S2M_HIP(h, hipSetDevice(h->device));
     int rc = ensure_kids(h, n_scans);
     if (rc) return rc;
+    // Work still queued on a slot's own stream (a preparation from s2m_batch_set_scan, a loop from s2m_slot_optimize_launch)
+    // uses the buffers this call rewrites: the handle's stream waits for it first.
+    for (int b = 0; b < n_scans; b++) {
+        S2M_HIP(h, hipEventRecord(h->prep_events[(size_t)b], h->branch_streams[(size_t)b]));
+        S2M_HIP(h, hipStreamWaitEvent(h->stream, h->prep_events[(size_t)b], 0));
+        h->prep_pending[(size_t)b] = 0;
+    }
     for (int b0 = 0; b0 < n_scans; b0 += kPrepSlots) {
         PrepTable t;
         const int nb = std::min(kPrepSlots, n_scans - b0);
@@ -1202,8 +1209,9 @@ int s2m_batch_set_scans(s2m_handle h, int n_scans, const void* const* scans, con
             s2m_context* k = h->kids[(size_t)(b0 + j)];
             if ((rc = adopt_map(h, k)) == S2M_OK) rc = scan_slot_prepare(k, scans[b0 + j], sizes[b0 + j], stride_bytes, on_device != 0, &t.s[j]);
             if (rc) {
-                // the slots prepared so far in this group have not been ordered: none of them holds a scan
-                for (int q = 0; q <= j; q++) h->kids[(size_t)(b0 + q)]->have_scan = false;
+                // no slot of this call holds a scan after a failure: the groups before this one were ordered, but a batch
+                // of which some scans are missing is of no use to the caller
+                for (int q = 0; q <= b0 + j; q++) h->kids[(size_t)q]->have_scan = false;
                 (void)hipStreamSynchronize(h->stream);
                 return fail(h, rc, k->err.c_str());
             }

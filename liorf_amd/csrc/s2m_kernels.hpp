@@ -303,6 +303,7 @@ __global__ __launch_bounds__(kPolarBlock) void k_polar_count(const PrepTable tbl
 __global__ __launch_bounds__(1024) void k_polar_prefix(const PrepTable tbl)
 {
     const PrepSlot& ps = tbl.s[blockIdx.y];
+    if (ps.n <= 0) return;                                // an empty slot of a batch (its row of the table holds no buffers)
     int32_t* __restrict__ H = ps.block_hist; const int nb = ps.npb; int32_t* __restrict__ counts = ps.counts;
     __shared__ int32_t seg[16][64];
     const int lane = threadIdx.x & 63, s = threadIdx.x >> 6;
@@ -329,6 +330,7 @@ __global__ __launch_bounds__(1024) void k_polar_prefix(const PrepTable tbl)
 __global__ __launch_bounds__(1024) void k_polar_scan(const PrepTable tbl)
 {
     const PrepSlot& ps = tbl.s[blockIdx.y];
+    if (ps.n <= 0) return;                                // an empty slot of a batch
     int32_t* __restrict__ counts = ps.counts; int32_t* __restrict__ start = ps.cell_start;
     __shared__ int32_t wsum[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -632,6 +634,7 @@ __device__ __forceinline__ void chunk_table_body(const int32_t* __restrict__ par
 __global__ __launch_bounds__(1024) void k_chunk_table(const PrepTable tbl)
 {
     const PrepSlot& ps = tbl.s[blockIdx.y];
+    if (ps.n <= 0) return;                                // an empty slot of a batch
     chunk_table_body(ps.chunk_parts, ps.n, ps.n_chunks, ps.capacity, ps.wave_table, ps.n_waves, nullptr, nullptr);
 }
 

@@ -54,6 +54,30 @@ def test_batch_equals_separate_calls_bitwise():
     gpu.close()
 
 
+def test_batch_with_an_empty_scan_skips_that_slot_only():
+    """Round-3 advisor finding: an empty laserCloudSurfLastDS (the reference skips a scan with too few features, :1300)
+    in a batch of non-empty scans made the shared ordering kernels write through the empty slot's null buffers.  The
+    empty slot reports skipped == 2 with its pose untouched, the others are bitwise those of separate calls; in the
+    middle, at the front and at the end of the batch, and on a handle whose slots held scans before."""
+    cfgs = [synth.make_config("small", scan_index=k) for k in range(3)]
+    m = synth.to_xyzi(cfgs[0]["map"])
+    full = [synth.to_xyzi(c["scan"]) for c in cfgs]
+    poses = np.stack([c["pose_init"] for c in cfgs]).astype(np.float32)
+    solo = [_solo(m, s, p) for s, p in zip(full, poses)]
+    empty = np.zeros((0, full[0].shape[1]), np.float32)
+    gpu = s2m.MapOptimizationS2M()
+    gpu.setInputCloud(m)
+    for hole in (1, 0, 2, 1):
+        scans = [empty if b == hole else full[b] for b in range(3)]
+        out, res = gpu.optimizeBatch(scans, poses)
+        for b in range(3):
+            if b == hole:
+                assert res[b].skipped == 2 and res[b].iters_run == 0 and np.array_equal(out[b], poses[b]), (hole, b)
+            else:
+                assert res[b].skipped == 0 and np.array_equal(out[b].view(np.uint32), solo[b][0].view(np.uint32)), (hole, b)
+    gpu.close()
+
+
 def test_batch_follows_map_and_parameter_changes(cfg_tiny, cfg_small):
     gpu = s2m.MapOptimizationS2M()
     for cfg in (cfg_small, cfg_tiny, cfg_small):                   # the map under the slots changes: certificates must not leak
