@@ -47,7 +47,7 @@ struct s2m_context {
     // map side
     DevBuf raw_map, map_sorted, m_counts, m_cell_start, m_cell_of, m_rank_of;
     // scan side
-    DevBuf raw_scan, qx, qy, qz, qperm, npos, nbr, cert, aux, plane_cache, plane_alt, npos_alt, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of, q_block_hist;
+    DevBuf raw_scan, qx, qy, qz, qperm, npos, front, cert, aux, plane_cache, plane_alt, npos_alt, chunk_parts, chunk_factor, wave_table, n_waves, q_counts, q_cell_start, q_cell_of, q_rank_of, q_block_hist;
     // shared
     DevBuf block_sums, partials, state, trace, dctx, mm, dbg_idx5, dbg_d2, dbg_flag, dbg_coeff, dbg_clk, sc_bins, sc_out;
     // voxel-grid stages that feed the path (section 8(f) F1/F2): staging for host clouds, transformed key frames, filtered clouds
@@ -352,7 +352,7 @@ int scan_slot_prepare(s2m_context* h, const void* pts, size_t n, size_t stride, 
     h->hctx.wpb = wpb;
     // cutting a dense first-launch pass to 32 lanes pays in the 8-wave shape (kitti64: launch 0 89 -> 69 us); the 128-register
     // build of the 16-wave shape loses more to the extra passes than it gains (ouster128 160 -> 182 us, dense1m 318 -> 345 us)
-    if (!h->tune_env) { h->hctx.tune[0] = (wpb == NW) ? kSplitRaw32 : (1 << 30); h->hctx.tune[1] = 1 << 30; }
+    if (!h->tune_env) { h->hctx.tune[0] = 1 << 30; h->hctx.tune[1] = 1 << 30; }
     h->hctx.nblocks = nblocks;
     h->hctx.table_cap = table_cap;
     h->ctx_dirty = true;
@@ -378,7 +378,7 @@ int scan_slot_prepare(s2m_context* h, const void* pts, size_t n, size_t stride, 
     if ((rc = ensure(h, h->npos_alt, sizeof(int32_t) * 5 * n))) return rc;
     if ((rc = ensure(h, h->cert, sizeof(float4) * n))) return rc;           // cert and aux are reset by k_scatter_scan
     if ((rc = ensure(h, h->aux, sizeof(int4) * n))) return rc;
-    if ((rc = ensure(h, h->nbr, sizeof(int32_t) * kNbrCap * n))) return rc;
+    if ((rc = ensure(h, h->front, sizeof(float4) * kNbrCap * n))) return rc;
     if ((rc = ensure(h, h->q_cell_start, sizeof(int32_t) * kPolarCells))) return rc;
     if ((rc = ensure(h, h->q_cell_of, sizeof(int32_t) * n))) return rc;
     if ((rc = ensure(h, h->q_rank_of, sizeof(int32_t) * n))) return rc;
@@ -414,7 +414,7 @@ int scan_slot_prepare(s2m_context* h, const void* pts, size_t n, size_t stride, 
     h->hctx.npos = h->npos.as<int32_t>();
     h->hctx.cert = h->cert.as<float4>();
     h->hctx.aux = h->aux.as<int4>();
-    h->hctx.nbr = h->nbr.as<int32_t>();
+    h->hctx.front = h->front.as<float4>();
     h->hctx.plane_cache = h->plane_cache.as<float4>();
     h->hctx.plane_alt = h->plane_alt.as<float4>();
     h->hctx.npos_alt = h->npos_alt.as<int32_t>();
@@ -853,7 +853,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->hctx.trace = reinterpret_cast<s2m_iter_trace*>(h->state.as<DevState>() + 1);
     params_to_ctx(h, prm);
     if (const char* e = getenv("S2M_ABLATE")) h->hctx.ablate = atoi(e);
-    h->hctx.tune[0] = kSplitRaw32; h->hctx.tune[1] = kSplitRaw16;
+    h->hctx.tune[0] = 1 << 30; h->hctx.tune[1] = 1 << 30;
     if (const char* e = getenv("S2M_TUNE")) { (void)sscanf(e, "%d,%d,%d,%d", &h->hctx.tune[0], &h->hctx.tune[1], &h->hctx.tune[2], &h->hctx.tune[3]); h->tune_env = true; }
     h->ctx_dirty = true;
     if (upload_ctx(h) != S2M_OK) return bail(S2M_ERR_HIP);
@@ -881,7 +881,7 @@ int s2m_destroy(s2m_handle h)
     for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
     for (hipEvent_t e : h->iter_events) (void)hipEventDestroy(e);
     DevBuf* bufs[] = { &h->raw_map, &h->map_sorted, &h->m_counts, &h->m_cell_start, &h->m_cell_of, &h->m_rank_of,
-                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->npos, &h->nbr, &h->cert, &h->aux, &h->plane_cache, &h->plane_alt, &h->npos_alt, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of, &h->q_block_hist,
+                       &h->raw_scan, &h->qx, &h->qy, &h->qz, &h->qperm, &h->npos, &h->front, &h->cert, &h->aux, &h->plane_cache, &h->plane_alt, &h->npos_alt, &h->chunk_parts, &h->chunk_factor, &h->wave_table, &h->n_waves, &h->q_counts, &h->q_cell_start, &h->q_cell_of, &h->q_block_hist,
                        &h->q_rank_of, &h->block_sums, &h->partials, &h->state, &h->dctx, &h->mm,
                        &h->dbg_idx5, &h->dbg_d2, &h->dbg_flag, &h->dbg_coeff, &h->dbg_clk, &h->sc_bins, &h->sc_out,
                        &h->vox_in, &h->vox_out, &h->frames_xf, &h->scan_ds, &h->map_ds,

@@ -796,11 +796,10 @@ __device__ __forceinline__ void jacobian_row(const float (&sc)[6], float px, flo
 // ------------------------------------------------------------------------------------------
 // shared constants and wave-level helpers of the registration kernel (s2m_register.hpp)
 // ------------------------------------------------------------------------------------------
-constexpr int kTilePts = 320;        // points per wave tile (5 KiB) after filtering
-constexpr int kTileRaw = 640;        // unfiltered points of one 64-row group a wave is willing to stream through the filter
-constexpr int kCand = 24;            // candidate-list capacity per lane (tile positions, uint16)
+constexpr int kTilePts = 512;        // points per wave tile (8 KiB) after filtering; a tile slot fits the low 9 bits of a sweep key
+constexpr int kTileRaw = 1024;       // unfiltered points of one 64-row group a wave is willing to stream through the filter
 constexpr int kRowMax = 256;         // boxes with more rows go straight to the gather path
-constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning (<= 5e-5)
+constexpr float kSlabMargin = 1e-3f; // covers the fp32 rounding of the cell binning of a local map (<= 5e-5 at 200 m extent; s2m_register.hpp adds 1e-6 per metre)
 constexpr uint64_t kKeyInf = ((uint64_t)0x7f800000u << 32) | 0x7fffffffu;
 
 // LDS written by this wave is read back by other lanes of the same wave: DS operations of one

@@ -55,16 +55,14 @@
 // (included inside namespace s2m by s2m_kernels.hpp)
 
 constexpr float kCertMargin = 2e-6f;   // metres; see tier A above
-constexpr float kNbrReach   = 0.15f;   // metres beyond the 5th neighbour that a search tries to cover with the neighbourhood ...
-constexpr float kTightBound = 0.62f;   // metres: a stored tuple whose 5th member is nearer than this now is taken to be (nearly) the answer
-constexpr float kNbrReachCold = 0.10f; // ... and beyond the gate when it has no tuple to start from (first launch of a scan)
-constexpr int   kWalkLanes = 64;       // a wave whose tile overflowed serves up to this many lanes one by one; beyond, every lane walks its own cells
-constexpr int   kNbr = kNbrCap;        // neighbourhood capacity (map positions per scan point)
-constexpr int   kLevels = 6;           // radii a search counts against at once
+constexpr float kNbrReach   = 0.15f;   // metres beyond the 5th neighbour that a search looks, so that what it learns about "everything else" reaches that far ...
+constexpr float kTightBound = 0.62f;   // metres: a front whose 5th member is nearer than this now is taken to be (nearly) the answer
+constexpr float kNbrReachCold = 0.10f; // ... and beyond the gate when it has nothing to start from (first launch of a scan)
+constexpr int   kWalkLanes = 64;       // a wave serves up to this many leftover lanes one by one; beyond, every lane walks its own cells
+constexpr int   kNbr = kNbrCap;        // members of a point's front: the six nearest map points it knew
 constexpr float kFragileSlack = 3e-5f; // a certificate with less slack than this may well fail in the steady state of the loop: such a lane prefetches
-constexpr int   kSplitRaw32 = 220;     // raw box points above which a tile pass of more than 32 lanes is cut to 32 lanes (consecutive lanes are neighbours: the box and
-constexpr int   kSplitRaw16 = 1 << 30; // the tile shrink, and the idle lanes share the sweeps) - and of more than 16 lanes to 16
-constexpr int   kServeLanes = 4;       // up to this many searching lanes are served one by one instead of staging a tile
+constexpr float kSlabRound = 1e-6f;    // rounding of the cell binning per metre of distance from the grid origin (3 roundings of 6e-8 each, see kSlabMargin)
+constexpr float kAbsRound = 2.4e-7f;   // two ulps of an absolute coordinate, per metre of it
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));
 
@@ -181,16 +179,30 @@ struct Fragile {
     bool on = false;
     v4i aux = { 0, 0, 0, 0 };
     int opos[5] = { 0, 0, 0, 0, 0 };
-    int front[6] = { 0, 0, 0, 0, 0, 0 };
-    v3f mm[6];
+    v4f fr[6];                                            // the front: x, y, z, position in map_sorted (bits)
     int alt[5] = { 0, 0, 0, 0, 0 };                       // the tuple the lane had before its present one, and that tuple's plane
     v4f alt_plane = { NAN, 0.0f, 0.0f, 0.0f };            // (valid if state bit 4 is set)
 };
 
+// The seven smallest 32-bit keys seen, ascending.  a[k-1] <= a[k] always, so the new a[k] is the median of the old
+// a[k-1], the old a[k] and the key: the key if it falls between them, a[k-1] if it pushes the list down, a[k] otherwise -
+// one v_med3_u32 per element, from the top down (each uses the old value below it), and a minimum for a[0].
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) { return max(min(a, b), min(max(a, b), c)); }
+__device__ __forceinline__ void near7_insert(uint32_t (&a)[7], uint32_t key)
+{
+#pragma unroll
+    for (int k = 6; k > 0; --k) a[k] = umed3(a[k - 1], a[k], key);
+    a[0] = min(a[0], key);
+}
+constexpr uint32_t kSlotBits = 9;                          // a tile slot in the low bits of a sweep key (kTilePts <= 512)
+constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1u;
+constexpr uint32_t kNoKey = 0xffffffffu;
+static_assert(kTilePts <= (1 << kSlotBits), "tile slots must fit the key's low bits");
+
 template <bool HOOK>
 __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, const GridDesc& g, gptr<const v4f> map,
                                                 gptr<const int32_t> cell_start, const float (&T)[12], float gatef, int ablate,
-                                                int2 chunk, int lane, v4f* lpts, int2* lrows, uint16_t* lcand,
+                                                int2 chunk, int lane, v4f* lpts, int2* lrows,
                                                 float px, float py, float pz, v4f cert, WaveProf& prof)
 {
     const int nq = cp->n_q;
@@ -215,27 +227,32 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 
     const auto auxp = G((v4i*)cp->aux);
     const auto nposp = G(cp->npos);
-    const auto nbrp = G(cp->nbr);
+    const auto frontp = G((v4f*)cp->front);
     const auto certp = G((v4f*)cp->cert);
     const auto planep = G((v4f*)cp->plane_cache);
     const float gate_r = cp->gate_r;
 
-    // ---- what the point remembers: its tuple (for change detection), the radius its neighbourhood covers
-    const bool lookB = HOOK ? fin : need;
+    // ---- what the point remembers, all of it in one round trip: its tuple (for change detection), its front - the six
+    // nearest map points it knew, with their coordinates - and the radius beyond which it knows nothing.  A point that has
+    // never been settled (a new scan: certificate all zero) remembers nothing and asks for nothing.
+    const bool fresh = cert.x == 0.0f && cert.y == 0.0f && cert.z == 0.0f && cert.w == 0.0f;
+    const bool lookB = (HOOK ? fin : need) && !fresh;
     int ost = 0, nb_n = 0;
-    float r_out = 0.0f, r7o = 0.0f;                      // r7o: every map point other than the first six members was at least this far from q_ref
+    float r_out = 0.0f;                                   // every map point other than the front members was at least this far from q_ref
     int opos[5] = { 0, 0, 0, 0, 0 };
-    int nfront[6] = { 0, 0, 0, 0, 0, 0 };                // the six front members of the neighbourhood, requested in the same round trip
-    if (lookB) {                                          // (meaningful only if the state word says the neighbourhood is valid)
+    v4f fr[kNbr];
+#pragma unroll
+    for (int k = 0; k < kNbr; k++) fr[k] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+    if (lookB) {                                          // (meaningful only if the state word says the front is valid)
         const v4i a = auxp[i];
 #pragma unroll
         for (int j = 0; j < 5; j++) opos[j] = nposp[(size_t)j * nq + i];
 #pragma unroll
-        for (int j = 0; j < 6; j++) nfront[j] = nbrp[(size_t)j * nq + i];
-        r_out = __int_as_float(a.x); ost = a.y; nb_n = min(max(a.z, 0), kNbr); r7o = __int_as_float(a.w);
+        for (int k = 0; k < kNbr; k++) fr[k] = frontp[(size_t)k * nq + i];
+        ost = a.y; nb_n = min(max(a.z, 0), kNbr); r_out = fminf(__int_as_float(a.x), __int_as_float(a.w));
     }
     const bool had5 = lookB && (ost & 4) != 0;
-    bool nbr_ok = lookB && (ost & 8) != 0;                // the stored neighbourhood holds every map point within r_out of q_ref (possibly none)
+    bool nbr_ok = lookB && (ost & 8) != 0;                // the stored front holds every map point within r_out of q_ref (possibly none)
     if (HOOK && valid && passA) {
         // certified lanes report the stored tuple in the STORED order with the distances measured now: a wrong
         // certificate shows up in the parity tests as a mis-ordered or wrong neighbour list
@@ -254,115 +271,43 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     Top6k top;                                            // the outcome: the six nearest as (d2 | position), ascending
 #pragma unroll
     for (int k = 0; k < 6; k++) top.key[k] = kKeyInf;
-    float rn = 0.0f;                                      // every map point outside the evaluated neighbourhood is at least this far away
-    float r7 = 0.0f;                                      // ... and every one other than the six nearest at least this far
+    float rn = 0.0f;                                      // every map point other than the six is at least this far away
     bool settled = false;                                 // the lane has its answer for this pose
+    v4f nb[6];                                            // coordinates of the six (search: from the tile; w is not the original index there)
+#pragma unroll
+    for (int k = 0; k < 6; k++) nb[k] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+    bool have_nb = false;
 
-    // ---- tier B: the six nearest of the remembered neighbourhood, measured at this pose.  Everything outside it is at
-    // least r_out - (distance moved since) away: if that is beyond the new 5th member the tuple is proved; if it is
-    // beyond the gate and fewer than 5 members are inside the gate, "not gated" is proved.
+    // ---- tier B: the front, measured at this pose (no memory access: its coordinates came with the state).  Everything
+    // else is at least r_out - (distance moved since) away: if that is beyond the new 5th member the tuple is proved; if it
+    // is beyond the gate and fewer than 5 members are inside the gate, "not gated" is proved.  A lane it does not settle
+    // takes the 5th distance along as the bound of its search.
+    float bound = gatef;                                  // upper bound of the 5th-neighbour distance (squared), capped at the gate
+    bool has_prior = false;
     {
-        // (a lane that moved farther than its neighbourhood reaches cannot prove anything from it: it does not fetch the members)
-        const bool ev = need && nbr_ok && !(ablate & 2) && (r_out - eps > 0.0f);
+        const bool ev = need && nbr_ok && !(ablate & 2);
         if (__ballot(ev)) {
-            const int nmax = wave_max_i32(ev ? nb_n : 0);
-            // A neighbourhood is stored with its six nearest members in front.  Those six first (positions, then the six
-            // reads - independent, 12 bytes each - then the insertions): they settle the lane on their own if everything
-            // else (>= r7o away at the reference position) is still beyond the 5th of them.  Only for lanes they do not
-            // settle are the other members read, and inserted only where some lane needs it.
             Top6k t;
 #pragma unroll
             for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
-            uint64_t k7 = kKeyInf;                         // the nearest member outside the six nearest
-            bool open = ev;                                // lanes not settled yet
-            int np6[6];                                    // the six members in front
-            {
-                int (&np_)[6] = np6;
 #pragma unroll
-                for (int k = 0; k < 6; k++) np_[k] = (ev && k < nb_n) ? nfront[k] : 0;
-                v3f mm[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) mm[k] = *reinterpret_cast<gptr<const v3f>>(&map[np_[k]]);
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const bool on = ev && k < nb_n;
-                    const float dx = sx - mm[k].x, dy = sy - mm[k].y, dz = sz - mm[k].z;
-                    const float d2 = (dx * dx + dy * dy) + dz * dz;                     // L2_Simple order
-                    top6k_insert(t, on ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)np_[k]) : kKeyInf);
-                }
-                const float r = r7o - eps;
-                const float d2_5 = __uint_as_float(key_hi(t.key[4]));
-                const bool in_gate = key_hi(t.key[4]) < 0x7f800000u && ((double)d2_5 < cp->gate_sq);
-                const bool ok = in_gate ? (sqrtf(d2_5) + kCertMargin < r) : (gate_r + kCertMargin < r);
-                if (open && ok) {
-#pragma unroll
-                    for (int q = 0; q < 6; q++) top.key[q] = t.key[q];
-                    rn = r_out - eps; r7 = r; settled = true; open = false;
-                }
+            for (int k = 0; k < kNbr; k++) {
+                const bool on = ev && k < nb_n;
+                float d2;
+                const uint64_t key = make_key(fr[k], sx, sy, sz, d2);
+                top6k_insert(t, on ? key : kKeyInf);
             }
-            if (__ballot(open) && nmax > 6) {
-                int np_[kNbr - 6];
+            const float r = r_out - eps;
+            const float d2_5 = __uint_as_float(key_hi(t.key[4]));
+            const bool have5 = key_hi(t.key[4]) < 0x7f800000u;
+            const bool in_gate = have5 && ((double)d2_5 < cp->gate_sq);
+            const bool ok = in_gate ? (sqrtf(d2_5) + kCertMargin < r) : (gate_r + kCertMargin < r);
+            if (ev && ok) {
 #pragma unroll
-                for (int k = 6; k < kNbr; k++) { np_[k - 6] = 0; if (k < nmax && open && k < nb_n) np_[k - 6] = nbrp[(size_t)k * nq + i]; }
-                v3f mm[kNbr - 6];
-#pragma unroll
-                for (int k = 6; k < kNbr; k++) {
-                    mm[k - 6] = v3f{ 0.0f, 0.0f, 0.0f };
-                    if (k < nmax) mm[k - 6] = *reinterpret_cast<gptr<const v3f>>(&map[np_[k - 6]]);
-                }
-#pragma unroll
-                for (int k = 6; k < kNbr; k++) {
-                    if (k < nmax) {                        // wave-uniform
-                        const bool on = open && k < nb_n;
-                        const float dx = sx - mm[k - 6].x, dy = sy - mm[k - 6].y, dz = sz - mm[k - 6].z;
-                        const float d2 = (dx * dx + dy * dy) + dz * dz;
-                        const uint64_t key = on ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)np_[k - 6]) : kKeyInf;
-                        if (__ballot(key < t.key[5])) { const uint64_t out = top6k_insert(t, key); k7 = (out < k7) ? out : k7; }
-                        else k7 = (key < k7) ? key : k7;     // the smallest key left outside the six: the 7th nearest
-                    }
-                }
-                // If a member from behind made it into the six nearest, the stored list is put in order again (the six nearest in
-                // front, the rest behind): the early out above and the 7th-nearest bound rely on that order.
-                bool moved = false;
-#pragma unroll
-                for (int q = 0; q < 6; q++) {
-                    bool infront = key_hi(t.key[q]) >= 0x7f800000u;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) infront = infront || ((int)key_lo(t.key[q]) == np6[k] && k < nb_n);
-                    moved = moved || !infront;
-                }
-                moved = moved && open;
-                if (__ballot(moved)) {
-                    int slot = 0;
-                    if (moved) {
-#pragma unroll
-                        for (int q = 0; q < 6; q++)
-                            if (key_hi(t.key[q]) < 0x7f800000u) { nbrp[(size_t)slot * nq + i] = (int)key_lo(t.key[q]); slot++; }
-                    }
-#pragma unroll
-                    for (int k = 0; k < kNbr; k++) {
-                        if (k < nmax) {
-                            const int pk = (k < 6) ? np6[k < 6 ? k : 0] : np_[k >= 6 ? k - 6 : 0];
-                            bool in6 = false;
-#pragma unroll
-                            for (int q = 0; q < 6; q++) in6 = in6 || (key_hi(t.key[q]) < 0x7f800000u && pk == (int)key_lo(t.key[q]));
-                            if (moved && k < nb_n && !in6 && slot < kNbr) { nbrp[(size_t)slot * nq + i] = pk; slot++; }
-                        }
-                    }
-                }
-            }
-            if (__ballot(open)) {
-                const float r = r_out - eps;
-                const float d2_5 = __uint_as_float(key_hi(t.key[4]));
-                const bool in_gate = key_hi(t.key[4]) < 0x7f800000u && ((double)d2_5 < cp->gate_sq);
-                const bool ok = in_gate ? (sqrtf(d2_5) + kCertMargin < r) : (gate_r + kCertMargin < r);
-                if (open && ok) {
-#pragma unroll
-                    for (int q = 0; q < 6; q++) top.key[q] = t.key[q];
-                    rn = r; settled = true;
-                    // the stored list has the six nearest in front again: everything else is the 7th nearest member and beyond
-                    r7 = (key_hi(k7) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(k7))) * 0.999999f, r) : r;
-                }
+                for (int q = 0; q < 6; q++) top.key[q] = t.key[q];
+                rn = r; settled = true;
+            } else if (ev && have5 && !(ablate & 16)) {
+                bound = fminf(d2_5, gatef); has_prior = true;
             }
         }
         if (HOOK) prof.n_b += __popcll(__ballot(settled));
@@ -374,54 +319,39 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     if (cmask) {
         if (HOOK) { prof.n_c += __popcll(cmask); prof.ts[0] = wall_clock64(); }
         if (searching) { nb_n = 0; nbr_ok = false; }
-        // Upper bound of the 5th-neighbour distance: the old tuple measured at this pose (any 5 distinct map points would
-        // do), capped at the gate.
-        float bound = gatef;
-        Top5k best;                                        // only the fallback sweep uses it
-#pragma unroll
-        for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
-        if (searching && had5 && !(ablate & 16)) {
-#pragma unroll
-            for (int j = 0; j < 5; j++) {
-                const v4f m = map[opos[j]];
-                float d2;
-                make_key(m, sx, sy, sz, d2);
-                top5k_insert(best, ((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)opos[j]);
-            }
-            if (key_hi(best.key[4]) < 0x7f800000u) bound = fminf(__uint_as_float(key_hi(best.key[4])), gatef);
-            else {
-#pragma unroll
-                for (int k = 0; k < 5; k++) best.key[k] = kKeyInf;
-            }
-        }
-        const bool has_prior = searching && best.key[4] != kKeyInf;
+        has_prior = has_prior && searching;
         const int cx = cell_coord(sx, g.ox, g.inv_e, g.nx);
         const int cy = cell_coord(sy, g.oy, g.inv_e, g.ny);
         const int cz = cell_coord(sz, g.oz, g.inv_e, g.nz);
         // squared slab distances of this query to the faces of its own cell: lower bounds of the
         // distance to anything in the neighbouring row / cell on that side (see kSlabMargin)
+        // (measured from the grid origin, like the binning itself: the map lives in the odometry frame, and at 20 km from its
+        // origin an absolute face coordinate would be rounded to a millimetre; what is left is the rounding of the binning,
+        // which grows with the extent of the local map - see kSlabMargin)
         const float E = g.e;
-        const float xlo = g.ox + (float)cx * E, ylo = g.oy + (float)cy * E, zlo = g.oz + (float)cz * E;
-        const float gxm = fmaxf(sx - xlo - kSlabMargin, 0.0f), gxp = fmaxf(xlo + E - sx - kSlabMargin, 0.0f);
-        const float gym = fmaxf(sy - ylo - kSlabMargin, 0.0f), gyp = fmaxf(ylo + E - sy - kSlabMargin, 0.0f);
-        const float gzm = fmaxf(sz - zlo - kSlabMargin, 0.0f), gzp = fmaxf(zlo + E - sz - kSlabMargin, 0.0f);
+        const float ux = sx - g.ox, uy = sy - g.oy, uz = sz - g.oz;
+        const float slab = kSlabMargin + kSlabRound * (fabsf(ux) + fabsf(uy) + fabsf(uz));
+        const float xlo = (float)cx * E, ylo = (float)cy * E, zlo = (float)cz * E;
+        const float gxm = fmaxf(ux - xlo - slab, 0.0f), gxp = fmaxf(xlo + E - ux - slab, 0.0f);
+        const float gym = fmaxf(uy - ylo - slab, 0.0f), gyp = fmaxf(ylo + E - uy - slab, 0.0f);
+        const float gzm = fmaxf(uz - zlo - slab, 0.0f), gzp = fmaxf(zlo + E - uz - slab, 0.0f);
         const float gx2m = gxm * gxm * 0.9999f, gx2p = gxp * gxp * 0.9999f;
         const float gy2m = gym * gym * 0.9999f, gy2p = gyp * gyp * 0.9999f;
         const float gz2m = gzm * gzm * 0.9999f, gz2p = gzp * gzp * 0.9999f;
         // How far this lane looks: a reach beyond its bound, but not beyond what its 3x3x3 cells cover for certain
         // (one whole cell past the nearest face of its own cell).  Every map point nearer than `be` is met.
-        const float cover = (E - kSlabMargin) + fminf(fminf(fminf(gxm, gxp), fminf(gym, gyp)), fminf(gzm, gzp));
+        const float cover = (E - slab) + fminf(fminf(fminf(gxm, gxp), fminf(gym, gyp)), fminf(gzm, gzp));
         const float sb = sqrtf(bound);
-        const bool tight = has_prior && sb < kTightBound;  // see the level layout of the tile path
+        const bool tight = has_prior && sb < kTightBound;
         const float be = searching ? fminf(sb + (tight ? kNbrReach : kNbrReachCold), cover) : 0.0f;
         const float be2 = fmaxf(be * be, bound);          // rows / cells are selected with this; never tighter than the bound itself
+        const float rim2 = be * be * 0.99999f;            // a tile point nearer than this is one of EVERY map point nearer than this
 
         // ---- tile passes.  A pass takes the first `group` searching lanes that are still to do: the box rows those lanes need
         // are sized and streamed through a filter into the wave's LDS tile, and the lanes are settled from the tile.  A box far
-        // larger than the lanes' own neighbourhoods (scattered points) is not worth staging, and neither is a tile for a
-        // handful of lanes: those are served one by one below.  When the tile of a pass would overflow (a dense part of the
-        // map under a wide wave), the pass is repeated with half the lanes - consecutive lanes are neighbours in space, so
-        // the box and with it the tile shrink - instead of serving all of them one by one.
+        // larger than the lanes' own neighbourhoods (scattered points) is not worth staging: those lanes are served one by one
+        // below.  When the tile of a pass would overflow (a dense part of the map under a wide wave), the pass is repeated with
+        // half the lanes - consecutive lanes are neighbours in space, so the box and with it the tile shrink.
         unsigned long long todo = cmask, pend = 0ull;
         int group = 64;
         while (todo) {
@@ -440,12 +370,12 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         const int R = nyb * nzb;                          // rows in the box
         if (HOOK) { prof.rows = R; prof.why = 0; }
         const float rmax2 = wave_max_f32(act ? be2 : 0.0f);
+        // (the filter box is compared in absolute coordinates: grown by their rounding as well)
+        const float slabw = wave_max_f32(act ? slab + kAbsRound * (fabsf(sx) + fabsf(sy) + fabsf(sz)) : 0.0f);
         const int tile_cap = kTilePts;
-        const float rr = sqrtf(rmax2) * 1.000001f + kSlabMargin;
+        const float rr = sqrtf(rmax2) * 1.000001f + slabw;
         const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
-        // (a short wave - 8, 16 or 32 points of a split chunk - whose lanes all search stages its tile and shares the sweeps)
-        const bool all_of_short = chunk.y <= 32 && amask == ((1ull << chunk.y) - 1ull);
-        const bool few = nA <= kServeLanes && !all_of_short && !(ablate & 128);      // a handful of lanes: served
+        const bool few = nA <= cp->tune[3] && !(ablate & 128);      // a handful of lanes may be served one by one instead (experiments: S2M_TUNE)
         bool tile = !(ablate & 64) && !few && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * max(nA, 8);
         if (HOOK && !tile) prof.why = 1;
         int nt = 0;                                       // tile fill, wave-uniform
@@ -476,43 +406,46 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             const int ptot = __builtin_amdgcn_readlane(wave_incl_scan_i32(len), 63);
             if (HOOK) prof.raw += ptot;
             if (ptot > kTileRaw) { tile = false; if (HOOK) prof.why = 2; break; }
-            // a dense box under a wide pass: both sweeps cost lanes x tile points - half the lanes see a smaller box, and the
-            // other half of the wave shares their sweeps
-            // (lanes with a tuple to start from count against tight radii and list few candidates: measured, the cut does not pay there)
-            if (__ballot(act && (cp->tune[2] ? tight : has_prior)) == 0ull &&
-                ((nA > 32 && ptot > cp->tune[0]) || (nA > 16 && nA <= 32 && ptot > cp->tune[1]))) { tile = false; if (HOOK) prof.why = 4; break; }
-            // ---- stage through the filter: 16 lanes per row, 8 rows in flight per pass; a point
+            // (experiments, S2M_TUNE: a dense box under a wide pass cut to 32 / 16 lanes - the sweep costs lanes x tile points)
+            if (((nA > 32 && ptot > cp->tune[0]) || (nA > 16 && nA <= 32 && ptot > cp->tune[1]))) { tile = false; if (HOOK) prof.why = 4; break; }
+            // ---- stage through the filter: 16 lanes per row, 16 rows in flight per pass (four loads per lane); a point
             // enters the tile only if it lies inside the lanes' point box grown by the largest radius.
             // Rows nobody marked, and marked rows that are empty, are squeezed out first (through LDS): every
-            // batch of 8 rows costs a dependent round trip to the map whatever it holds.
+            // batch of rows costs a dependent round trip to the map whatever it holds.
             const int sub = lane >> 4, l16 = lane & 15;
             const unsigned long long nzrows = __ballot(len > 0);
             const int nr = __popcll(nzrows);
             if (len > 0) lrows[__popcll(nzrows & ((1ull << lane) - 1ull))] = make_int2(gs, len);
             wave_lds_sync();
-            for (int cb = 0; cb < nr && tile; cb += 8) {
-                const int ca = cb + sub, cc = cb + 4 + sub;
-                int gsa = 0, na = 0, gsc = 0, nn = 0;
-                if (ca < nr) { const int2 rw = lrows[ca]; gsa = rw.x; na = rw.y; }
-                if (cc < nr) { const int2 rw = lrows[cc]; gsc = rw.x; nn = rw.y; }
-                const int npass = wave_max_i32(max(na, nn));
-                for (int k0 = 0; k0 < npass; k0 += 16) {
+            for (int cb = 0; cb < nr && tile; cb += 16) {
+                int gsr[4], nrw[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int c = cb + 4 * u + sub;
+                    gsr[u] = 0; nrw[u] = 0;
+                    if (c < nr) { const int2 rw = lrows[c]; gsr[u] = rw.x; nrw[u] = rw.y; }
+                }
+                const int npass = wave_max_i32(max(max(nrw[0], nrw[1]), max(nrw[2], nrw[3])));
+                for (int k0 = 0; k0 < npass && tile; k0 += 16) {
                     const int k = k0 + l16;
-                    v4f pa_v = { 0, 0, 0, 0 }, pc_v = { 0, 0, 0, 0 };
-                    const bool ha = k < na, hc = k < nn;
-                    if (ha) pa_v = map[gsa + k];
-                    if (hc) pc_v = map[gsc + k];
-                    pa_v.w = __int_as_float(gsa + k);     // the tile keeps the map POSITION as the key's low word
-                    pc_v.w = __int_as_float(gsc + k);
-                    const bool ia = ha && pa_v.x >= fx0 && pa_v.x <= fx1 && pa_v.y >= fy0 && pa_v.y <= fy1 && pa_v.z >= fz0 && pa_v.z <= fz1;
-                    const bool ic = hc && pc_v.x >= fx0 && pc_v.x <= fx1 && pc_v.y >= fy0 && pc_v.y <= fy1 && pc_v.z >= fz0 && pc_v.z <= fz1;
-                    const unsigned long long ma = __ballot(ia), mc = __ballot(ic);
-                    const int an = __popcll(ma), cn = __popcll(mc);
-                    if (nt + an + cn > tile_cap) { tile = false; if (HOOK) prof.why = 3; break; }
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    if (ia) lpts[nt + __popcll(ma & below)] = pa_v;
-                    if (ic) lpts[nt + an + __popcll(mc & below)] = pc_v;
-                    nt += an + cn;
+                    v4f pv[4];
+                    bool hv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        hv[u] = k < nrw[u];
+                        pv[u] = v4f{ 0, 0, 0, 0 };
+                        if (hv[u]) pv[u] = map[gsr[u] + k];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        pv[u].w = __int_as_float(gsr[u] + k);     // the tile keeps the map POSITION as the key's low word
+                        const bool in = hv[u] && pv[u].x >= fx0 && pv[u].x <= fx1 && pv[u].y >= fy0 && pv[u].y <= fy1 && pv[u].z >= fz0 && pv[u].z <= fz1;
+                        const unsigned long long mk = __ballot(in);
+                        const int cn = __popcll(mk);
+                        if (nt + cn > tile_cap) { tile = false; if (HOOK) prof.why = 3; break; }
+                        if (in) lpts[nt + __popcll(mk & ((1ull << lane) - 1ull))] = pv[u];
+                        nt += cn;
+                    }
                 }
             }
         }
@@ -528,193 +461,64 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         {
             wave_lds_sync();
             if (HOOK) { prof.mode = 1; prof.pts = nt; }
-            // The radii (squared) the tile points are counted against, widest first.  With a tuple to start from: from the
-            // reach down to the bound itself; without one: the reach, the gate, and fractions of the gate.  The neighbourhood
-            // becomes the widest of them that holds at most kNbr points.
-            float tl[kLevels];
-            // (a tuple to start from that has gone stale - the pose moved far, its 5th member is now near or beyond the gate - says
-            // little about where the 5th neighbour really is: such a lane counts like one without a tuple, in fractions of its bound)
-            if (tight) {
-                const float st[kLevels] = { kNbrReach, 0.10f, 0.06f, 0.03f, 0.012f, 0.0f };
+            // ---- the sweep: every lane keeps the seven nearest tile points by 32-bit keys - the bits of the squared distance with
+            // the low kSlotBits replaced by the tile slot.  Such a key orders two points correctly unless their distances agree to
+            // 2^-14 (18 um at 0.6 m); its distance part, the low bits cleared, is a LOWER bound of the point's true squared
+            // distance.  Eight subtractions / multiplications / additions (packed: two tile points per instruction), one
+            // v_and_or and seven v_med3 / v_min per lane and tile point, whatever the lane finds.
+            uint32_t a[7];
 #pragma unroll
-                for (int k = 0; k < kLevels; k++) { const float rr_ = fminf(sb + st[k], be); tl[k] = fmaxf(rr_ * rr_, bound); }
-                tl[kLevels - 1] = bound;
-            } else {
-                const float fr[kLevels] = { 0.0f, 1.0f, 1.0f / 1.6f, 1.0f / 2.56f, 1.0f / 4.1f, 1.0f / 6.55f };
-#pragma unroll
-                for (int k = 0; k < kLevels; k++) tl[k] = fminf(bound * fr[k], be2);      // bound = the gate without a tuple
-                tl[0] = be2;
-            }
-            // Idle lanes join in.  With nC <= 32 searching lanes, kq = 2, 4 or 8 lanes share one searching point: the wave is
-            // cut into kq parts of nslot = 64 / kq lanes, lane l works for slot l % nslot - the searching lane of that rank -
-            // and sweeps every kq-th tile point; counts, lists and the rim are combined across the parts, and the searching
-            // lane of rank r picks its result up from lane r (part 0 of its slot).  kq = 1: every lane works for itself.
-            const int kq = (nt <= 16 || nA > 32) ? 1 : ((nA > 16) ? 2 : ((nA > 8) ? 4 : 8));
-            const int nslot = 64 / kq, part = lane / nslot;
-            int own = lane;                                   // the searching lane this lane works for
-            int col = lane;                                   // the lane whose results (and LDS column) are mine: my rank among the searching lanes
-            bool q_search = act;
-            if (kq > 1) {
-                int* lown = reinterpret_cast<int*>(lrows);    // (the row table is not needed any more)
-                const int rank = __popcll(amask & ((1ull << lane) - 1ull));
-                if (act) lown[rank] = lane;
-                wave_lds_sync();
-                const int s_ = lane & (nslot - 1);
-                q_search = s_ < nA;
-                own = q_search ? lown[s_] : lane;
-                col = act ? rank : lane;
-            }
-            float qx_ = sx, qy_ = sy, qz_ = sz;
-            float ql_[kLevels];
-#pragma unroll
-            for (int k = 0; k < kLevels; k++) ql_[k] = tl[k];
-            bool q_prior = tight;
-            if (kq > 1) {
-                qx_ = __shfl(sx, own, 64); qy_ = __shfl(sy, own, 64); qz_ = __shfl(sz, own, 64);
-#pragma unroll
-                for (int k = 0; k < kLevels; k++) ql_[k] = __shfl(tl[k], own, 64);
-                q_prior = __shfl((int)tight, own, 64) != 0;
-            }
-            // ---- count the tile points inside the kLevels radii of every searching lane (branch-free)
-            int c[kLevels];
-#pragma unroll
-            for (int k = 0; k < kLevels; k++) c[k] = 0;
+            for (int k = 0; k < 7; k++) a[k] = kNoKey;
             {
-                int j = part;
-                for (; j + kq < nt; j += 2 * kq) {            // two LDS reads in flight
-                    const v4f m0 = lpts[j], m1 = lpts[j + kq];
+                int j = 0;
+                for (; j + 2 <= nt; j += 2) {
+                    const v4f m0 = lpts[j], m1 = lpts[j + 1];
                     float d0, d1;
-                    make_key(m0, qx_, qy_, qz_, d0); make_key(m1, qx_, qy_, qz_, d1);
-#pragma unroll
-                    for (int k = 0; k < kLevels; k++) c[k] += ((d0 <= ql_[k]) ? 1 : 0) + ((d1 <= ql_[k]) ? 1 : 0);
+                    make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
+                    near7_insert(a, (__float_as_uint(d0) & ~kSlotMask) | (uint32_t)j);
+                    near7_insert(a, (__float_as_uint(d1) & ~kSlotMask) | (uint32_t)(j + 1));
                 }
-                for (; j < nt; j += kq) {
-                    float d; make_key(lpts[j], qx_, qy_, qz_, d);
-#pragma unroll
-                    for (int k = 0; k < kLevels; k++) c[k] += (d <= ql_[k]) ? 1 : 0;
-                }
-            }
-            for (int m = nslot; m < 64; m <<= 1) {
-#pragma unroll
-                for (int k = 0; k < kLevels; k++) c[k] += __shfl_xor(c[k], m, 64);
-            }
-            // the widest level that fits; it has to hold the tuple (5 points) unless even the gate holds fewer than 5
-            // (a tuple to start from whose 5th member is beyond the gate has bound = gate: the last level counts the gate)
-            int cl = c[kLevels - 1];
-            float lvl2 = ql_[kLevels - 1];
-#pragma unroll
-            for (int k = kLevels - 2; k >= 0; k--) { const bool fits = c[k] <= kNbr; lvl2 = fits ? ql_[k] : lvl2; cl = fits ? c[k] : cl; }
-            const int c_gate = q_prior ? c[kLevels - 1] : c[1];
-            const bool q_fallback = q_search && (cl > kNbr || (cl < 5 && c_gate >= 5));
-            const bool q_lister = q_search && !q_fallback;
-            // ---- the neighbourhood: tile slots inside the level, written down in a second branch-free sweep; the nearest
-            // tile point beyond the level tells how far the neighbourhood really reaches
-            int cc = 0;
-            float mo = INFINITY;
-            if (q_lister) {
-                int j = part;
-                for (; j + 3 * kq < nt; j += 4 * kq) {        // four LDS reads in flight
-                    const v4f m0 = lpts[j], m1 = lpts[j + kq], m2 = lpts[j + 2 * kq], m3 = lpts[j + 3 * kq];
-                    float d0, d1, d2v, d3;
-                    make_key(m0, qx_, qy_, qz_, d0); make_key(m1, qx_, qy_, qz_, d1);
-                    make_key(m2, qx_, qy_, qz_, d2v); make_key(m3, qx_, qy_, qz_, d3);
-                    if (d0 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
-                    if (d1 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + kq); cc++; }
-                    if (d2v <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 2 * kq); cc++; }
-                    if (d3 <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)(j + 3 * kq); cc++; }
-                    mo = fminf(fminf(mo, (d0 > lvl2) ? d0 : INFINITY), (d1 > lvl2) ? d1 : INFINITY);
-                    mo = fminf(fminf(mo, (d2v > lvl2) ? d2v : INFINITY), (d3 > lvl2) ? d3 : INFINITY);
-                }
-                for (; j < nt; j += kq) {
-                    float d; make_key(lpts[j], qx_, qy_, qz_, d);
-                    if (d <= lvl2 && cc < kNbr) { lcand[cc * 64 + lane] = (uint16_t)j; cc++; }
-                    mo = fminf(mo, (d > lvl2) ? d : INFINITY);
+                if (j < nt) {
+                    float d0;
+                    make_key(lpts[j], sx, sy, sz, d0);
+                    near7_insert(a, (__float_as_uint(d0) & ~kSlotMask) | (uint32_t)j);
                 }
             }
-            bool fallback = act && q_fallback;
-            if (kq > 1) {
-                // the lists of a slot's parts go into the column of its part 0, where the searching lane finds them
-                wave_lds_sync();
-                for (int m = nslot; m < 64; m <<= 1) mo = fminf(mo, __shfl_xor(mo, m, 64));
-                int tot = cc;
-                for (int pp = 1; pp < kq; pp++) {
-                    const int n_pp = __shfl(cc, (lane & (nslot - 1)) + pp * nslot, 64);
-                    if (part == 0 && q_lister) {
-                        for (int k = 0; k < n_pp && tot < kNbr; k++) { lcand[tot * 64 + lane] = lcand[k * 64 + lane + pp * nslot]; tot++; }
-                    }
-                }
-                cc = __shfl(tot, col, 64);
-                mo = __shfl(mo, col, 64);
-                lvl2 = __shfl(lvl2, col, 64);
-                const int fb_col = __shfl((int)q_fallback, col, 64);       // (not inside a && / ?: - every lane has to take part in a shuffle)
-                fallback = act & (fb_col != 0);
+            // ---- the six nearest by key, measured exactly and put in exact order; beyond the reach nothing is known, so a
+            // point farther than that is no member.  Every tile point other than the six has a key >= a[6]: its true squared
+            // distance is at least a[6]'s distance part.  The answer stands if the exact 5th distance is below that bound;
+            // otherwise (a near-tie the keys cannot resolve: rare) the lane is served exactly below.
+            Top6k t;
+#pragma unroll
+            for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const bool have = act && a[k] != kNoKey;
+                const int jk = have ? (int)(a[k] & kSlotMask) : 0;
+                float d2;
+                make_key(lpts[jk], sx, sy, sz, d2);
+                top6k_insert(t, (have && d2 <= rim2) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)jk) : kKeyInf);
             }
-            const bool lister = act && !fallback;
-            if (HOOK) { prof.n_fb = __popcll(__ballot(fallback)); prof.reach_mm = (int)(rr * 1000.0f); prof.kq = kq; }
-            if (!lister) cc = 0;
-            wave_lds_sync();
-            // ---- its six nearest (the lanes insert their k-th member together), then the neighbourhood goes to memory with
-            // those six in front
-            {
-                const int cmax = wave_max_i32(cc);
-                if (HOOK) prof.cmax = cmax;
-                Top6k t;
+            const float lb7 = (a[6] != kNoKey) ? __uint_as_float(a[6] & ~kSlotMask) : INFINITY;
+            const uint32_t h5 = key_hi(t.key[4]);
+            const bool sure = !(h5 < 0x7f800000u) || (__uint_as_float(h5) < lb7);
+            const unsigned long long unsure_m = __ballot(act && !sure);
+            pend |= unsure_m;
+            if (HOOK) prof.n_fb = __popcll(unsure_m);
+            if (act && sure) {
+                int n6 = 0;
 #pragma unroll
-                for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
-                uint64_t k7 = kKeyInf;
-                v4f mk = lpts[min((int)lcand[col], kTilePts - 1)];
-                for (int k = 0; k < cmax; k++) {
-                    const v4f mn_ = lpts[min((int)lcand[min(k + 1, kCand - 1) * 64 + col], kTilePts - 1)];
-                    float d2;
-                    const uint64_t key = make_key(mk, sx, sy, sz, d2);
-                    const uint64_t out = top6k_insert(t, (lister && k < cc) ? key : kKeyInf);
-                    k7 = (out < k7) ? out : k7;
-                    mk = mn_;
+                for (int k = 0; k < 6; k++) {
+                    const bool on = key_hi(t.key[k]) < 0x7f800000u;
+                    const v4f m = lpts[on ? (int)key_lo(t.key[k]) : 0];
+                    nb[k] = on ? m : v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+                    top.key[k] = on ? (((uint64_t)key_hi(t.key[k]) << 32) | (uint32_t)__float_as_int(m.w)) : kKeyInf;
+                    n6 += on ? 1 : 0;
                 }
-                if (lister) {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) top.key[k] = t.key[k];
-                    // every tile point within the level is a member, the nearest beyond it is `mo` away, and beyond the reach
-                    // nothing is known
-                    nb_n = cc; rn = sqrtf((cp->ablate & 256) ? lvl2 : fminf(fmaxf(mo, lvl2), be * be)) * 0.999999f; nbr_ok = true; settled = true;
-                    r7 = (key_hi(k7) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(k7))), rn) : rn;
-                    int slot = 0;
-#pragma unroll
-                    for (int k = 0; k < 6; k++)
-                        if (key_hi(t.key[k]) < 0x7f800000u) { nbrp[(size_t)slot * nq + i] = (int)key_lo(t.key[k]); slot++; }
-                    for (int k = 0; k < cc; k++) {
-                        const int p = __float_as_int(lpts[min((int)lcand[k * 64 + col], kTilePts - 1)].w);
-                        bool in6 = false;
-#pragma unroll
-                        for (int j = 0; j < 6; j++) in6 = in6 || (uint32_t)p == key_lo(t.key[j]);
-                        if (!in6 && slot < kNbr) { nbrp[(size_t)slot * nq + i] = p; slot++; }
-                    }
-                }
+                nb_n = n6; nbr_ok = true; settled = true; have_nb = true;
+                rn = sqrtf(fminf(lb7, rim2)) * 0.999999f;
             }
-            // ---- fallback: the exact top-5 by a full sweep of the tile (no neighbourhood: the lane searches again next time)
-            if (__ballot(fallback)) {
-                uint32_t tieb = 0xffffffffu;
-                if (fallback) {
-                    int j = 0;
-                    for (; j + 4 <= nt; j += 4) {
-                        const v4f m0 = lpts[j], m1 = lpts[j + 1], m2 = lpts[j + 2], m3 = lpts[j + 3];
-                        consider(best, bound, gatef, tieb, m0, sx, sy, sz);
-                        consider(best, bound, gatef, tieb, m1, sx, sy, sz);
-                        consider(best, bound, gatef, tieb, m2, sx, sy, sz);
-                        consider(best, bound, gatef, tieb, m3, sx, sy, sz);
-                    }
-                    for (; j < nt; j++) consider(best, bound, gatef, tieb, lpts[j], sx, sy, sz);
-                    if (best.key[4] != kKeyInf && tieb == key_hi(best.key[4]))
-                        exact_top5_of_cells(map, cell_start, g, cx, cy, cz, sx, sy, sz, gatef, best);
-#pragma unroll
-                    for (int k = 0; k < 5; k++) top.key[k] = best.key[k];
-                    top.key[5] = kKeyInf;
-                    // every point within the bound was considered (members of a stale tuple beyond it may linger in the set:
-                    // such a lane is not gated, and nothing is known beyond the bound)
-                    rn = sqrtf(fminf(bound, be2)) * 0.999999f; r7 = rn;
-                    settled = true;
-                }
-            }
+            wave_lds_sync();                              // (the next pass stages into the same tile)
         }
         }   // tile passes
         if (HOOK) prof.ts[2] = wall_clock64();
@@ -782,34 +586,33 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 }
                 if (lane == L) {
                     // members: the nearest six that lie inside what the walked cells cover for certain; the radius: the 7th, or that rim
-                    const float rim2 = be * be * 0.99999f;
                     int n6 = 0;
 #pragma unroll
                     for (int r = 0; r < 6; r++) {
                         const bool have = key_hi(found[r]) < 0x7f800000u && __uint_as_float(key_hi(found[r])) <= rim2;
                         top.key[r] = have ? found[r] : kKeyInf;
                         n6 += have ? 1 : 0;
-                        if (have) nbrp[(size_t)r * nq + i] = (int)key_lo(found[r]);
                     }
                     const bool seven = n6 == 6 && key_hi(found[6]) < 0x7f800000u;
                     rn = sqrtf(fminf(seven ? __uint_as_float(key_hi(found[6])) : INFINITY, rim2)) * 0.999999f;
-                    nb_n = n6; nbr_ok = true; settled = true; r7 = rn;
+                    nb_n = n6; nbr_ok = true; settled = true; have_nb = false;
                 }
                 wave_lds_sync();                                  // the next lane's keys go to the same LDS area
             }
         }
         // ---- lanes left to walk their own 3x3x3 cells (a tile that overflowed under many lanes, or more candidates than the
-        // served path holds): exact, slow, and without a neighbourhood - the point searches again next launch
+        // served path holds): exact, slow, and without a front - the point searches again next launch
         const bool walker = searching && ((walk >> lane) & 1ull) != 0ull;
         if (__ballot(walker)) {
             if (HOOK) prof.mode = 3;
             if (walker) {
+                Top5k best;
                 exact_top5_of_cells(map, cell_start, g, cx, cy, cz, sx, sy, sz, gatef, best);
 #pragma unroll
                 for (int k = 0; k < 5; k++) top.key[k] = best.key[k];
                 top.key[5] = kKeyInf;
-                rn = (best.key[4] != kKeyInf) ? sqrtf(__uint_as_float(key_hi(best.key[4]))) : gate_r; r7 = rn;
-                settled = true;
+                rn = (best.key[4] != kKeyInf) ? sqrtf(__uint_as_float(key_hi(best.key[4]))) : gate_r;
+                settled = true; have_nb = false; nbr_ok = false;
             }
         }
         if (HOOK) prof.ts[3] = wall_clock64();
@@ -834,6 +637,8 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                     for (int k = 0; k < 5; k++) fk[k] = ex.key[k];
                 }
                 fk[5] = kKeyInf;                           // (whoever is sixth stands at the 5th distance: no slack, see below)
+                have_nb = false;                           // (the coordinates in hand belong to the six the sweep found)
+                if (searching) nbr_ok = false;             // no front is kept for such a point: it searches again next launch
             }
         }
         tie56 = btie;
@@ -846,18 +651,20 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 #pragma unroll
     for (int k = 0; k < 5; k++) tie_adj = tie_adj || (key_hi(fk[k]) == key_hi(fk[k + 1]) && key_hi(fk[k]) < 0x7f800000u);
     tie_adj = tie_adj && upd;
-    // Coordinates + original indices of the six nearest (L2-warm) - only where they are needed: the plane has to be fitted
-    // (new tuple, or a tuple that was not gated before), or equal distances have to be put in index order.  A lane that
-    // re-measured and found its tuple unchanged (the lanes that do so in every launch of the steady state: near-ties
-    // between two of their neighbour distances leave them no slack) keeps its plane and skips the round trip.
-    const bool fetch6 = upd && (HOOK || changed || tie_adj || (ablate & 32) != 0 ||
-                                (complete && ((double)__uint_as_float(key_hi(fk[4])) < cp->gate_sq) && (ost & 3) == 0));
-    v4f nb[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) nb[k] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const bool store_front = upd && searching && nbr_ok;  // a search's six become the point's front
+    // Coordinates + original indices of the six nearest from the map (L2-warm) - only where they are needed and not in hand:
+    // the plane has to be fitted (new tuple, or a tuple that was not gated before) or the front stored by a lane that was not
+    // settled from a tile, or equal distances have to be put in index order (the tile carries positions, not original
+    // indices).  A lane that re-measured and found its tuple unchanged keeps its plane and skips the round trip.
+    const bool want_nb = upd && (changed || store_front || (ablate & 32) != 0 ||
+                                 (complete && ((double)__uint_as_float(key_hi(fk[4])) < cp->gate_sq) && (ost & 3) == 0));
+    const bool fetch6 = upd && (HOOK || tie_adj || (want_nb && !have_nb));
     if (__ballot(fetch6)) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) nb[k] = map[(fetch6 && key_hi(fk[k]) < 0x7f800000u) ? (int)key_lo(fk[k]) : 0];
+        for (int k = 0; k < 6; k++) {
+            const v4f m = map[(fetch6 && key_hi(fk[k]) < 0x7f800000u) ? (int)key_lo(fk[k]) : 0];
+            nb[k] = fetch6 ? m : nb[k];
+        }
     }
     {
         if (__ballot(tie_adj)) {
@@ -909,11 +716,10 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             planep[i] = pl;
             pst = 0;
         }
-        // the certificate for the launches to come: d1..d5, then the nearest of anything else - the 6th member of the
-        // neighbourhood or its rim
+        // the certificate for the launches to come: d1..d5, then the nearest of anything else - the 6th of the six or
+        // whatever lies beyond them
         float slack = 0.0f;
-        const float rest = fminf(r7, rn);                 // everything that is not one of the six keys is at least this far away
-        const float d6 = (key_hi(fk[5]) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(fk[5]))), rest) : rest;
+        const float d6 = (key_hi(fk[5]) < 0x7f800000u) ? fminf(sqrtf(__uint_as_float(key_hi(fk[5]))), rn) : rn;
         if (gated) {
             float dk[5];
 #pragma unroll
@@ -924,12 +730,13 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             slack = fminf(0.5f * gap - kCertMargin, gate_r - dk[4] - 2.0f * kCertMargin);
         } else {
             // not gated: stays so while the 5th nearest map point (a member beyond the gate, or something outside the
-            // neighbourhood) cannot come inside the gate
-            const float f5 = complete ? fminf(sqrtf(d2_5), rest) : rest;
+            // six) cannot come inside the gate
+            const float f5 = complete ? fminf(sqrtf(d2_5), rn) : rn;
             slack = f5 - gate_r - 2.0f * kCertMargin;
         }
         slack = (slack > 0.0f && !tie56) ? slack : 0.0f;                              // also NaN -> 0
-        const v4f cnew = { sx, sy, sz, slack };
+        // (a certificate is never all zero - that is the mark of a point that has never been settled)
+        const v4f cnew = { sx, sy, sz, (slack == 0.0f && sx == 0.0f && sy == 0.0f && sz == 0.0f) ? -1.0f : slack };
         certp[i] = cnew;
         // The tuple a lane leaves is kept with its plane (plane_alt / npos_alt, state bit 4): two nearly equidistant neighbours swap
         // places back and forth with the micro-steps of the converged loop, and the certify kernels exchange the two planes
@@ -941,8 +748,15 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 #pragma unroll
             for (int k = 0; k < 5; k++) G(cp->npos_alt)[(size_t)k * nq + i] = opos[k];
         }
+        if (store_front) {
+#pragma unroll
+            for (int k = 0; k < kNbr; k++) {
+                const v4f f = { nb[k].x, nb[k].y, nb[k].z, __int_as_float((int)key_lo(fk[k])) };
+                if (k < nb_n) frontp[(size_t)k * nq + i] = f;
+            }
+        }
         const v4i anew = { __float_as_int(rn), pst | (complete ? 4 : 0) | (nbr_ok ? 8 : 0) | (keep_old ? 16 : (ost & 16)), nbr_ok ? nb_n : 0,
-                           __float_as_int(fminf(r7, rn)) };
+                           __float_as_int(rn) };
         auxp[i] = anew;
         if (complete && changed) {
 #pragma unroll
@@ -1299,17 +1113,14 @@ __global__ __launch_bounds__(NW / EPW * 64, MINW) void k_certify_lean(const Slot
 #pragma unroll
                 for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
                 {
-                    int front[6];
+                    v4f fr[6];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) front[j] = G(cp->nbr)[(size_t)j * nq + i];
-                    const auto map = G((const v4f*)cp->map_sorted);
+                    for (int j = 0; j < 6; j++) fr[j] = G((const v4f*)cp->front)[(size_t)j * nq + i];
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
-                        const bool on = okl && k < nfr;
-                        const v3f mm = *reinterpret_cast<gptr<const v3f>>(&map[on ? front[k] : 0]);
-                        const float dx = sx - mm.x, dy = sy - mm.y, dz = sz - mm.z;
-                        const float d2 = (dx * dx + dy * dy) + dz * dz;                 // L2_Simple order
-                        top6k_insert(t, on ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)front[k]) : kKeyInf);
+                        float d2;
+                        const uint64_t key = make_key(fr[k], sx, sy, sz, d2);            // L2_Simple order; low word: the member's map position
+                        top6k_insert(t, (okl && k < nfr) ? key : kKeyInf);
                     }
                 }
                 const float r = __int_as_float(aux.w) - eps;                            // everything outside the six is at least this far away
@@ -1404,7 +1215,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     __shared__ v4f     s_pts[kTileWaves][kHasSearch ? kTilePts : 1];   // per wave: the tile, or (gather path) the lane's 9 (start, end) pairs
     static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
     __shared__ double  red[CNW][32];
-    __shared__ uint16_t s_cand[kTileWaves][kHasSearch ? kCand * 64 : 1];   // per wave: tile positions of each lane's candidates, [k][lane]
     __shared__ int2    s_rows[kTileWaves][kHasSearch ? 64 : 1];            // per wave: the non-empty box rows of the current row group
     __shared__ float   s_lm_out[8];                  // pose + loop-ended flag published by lm_close_iteration
     __shared__ LmShared s_lm;                        // (kCertify: the close has no tile area to borrow)
@@ -1470,7 +1280,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     // closes: the certify kernel of the same launch or k_finalize has stored the pose of this launch.)
     Fragile frag;
 #pragma unroll
-    for (int k = 0; k < 6; k++) frag.mm[k] = v3f{ 0.0f, 0.0f, 0.0f };
+    for (int k = 0; k < 6; k++) frag.fr[k] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
     float T[12], sc6[6];
     if (!solve_prev && st->T_valid) {
 #pragma unroll
@@ -1496,20 +1306,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
 #pragma unroll
                     for (int j = 0; j < 5; j++) frag.opos[j] = G(cp->npos)[(size_t)j * nq + i];
 #pragma unroll
-                    for (int j = 0; j < 6; j++) frag.front[j] = G(cp->nbr)[(size_t)j * nq + i];
+                    for (int j = 0; j < 6; j++) frag.fr[j] = G((const v4f*)cp->front)[(size_t)j * nq + i];
 #pragma unroll
                     for (int j = 0; j < 5; j++) frag.alt[j] = G(cp->npos_alt)[(size_t)j * nq + i];
                     frag.alt_plane = G((const v4f*)cp->plane_alt)[i];
                 }
             };
-            auto late = [&]() {
-                if (frag.on) {
-                    const bool ok = (frag.aux.y & 8) != 0;
-                    const int n = min(max(frag.aux.z, 0), kNbr);
-#pragma unroll
-                    for (int k = 0; k < 6; k++) frag.mm[k] = *reinterpret_cast<gptr<const v3f>>(&map[(ok && k < n) ? frag.front[k] : 0]);
-                }
-            };
+            auto late = [&]() {};
             const bool ended = lm_close_iteration<NW * 64, false>(cp, st, nb_act, launch - 1, blockIdx.x == 0, false, pose0, degen0,
                                                                  sh, s_lm_out, pose, HOOK ? lm_stamps : nullptr, early, late);
             if (ended) return;
@@ -1546,7 +1349,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                         cert = G((const v4f*)cp->cert)[i];
                     }
                 }
-                associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
+                associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                                       px, py, pz, cert, prof);
             }
             if (HOOK) clk1 = wall_clock64();
@@ -1583,9 +1386,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                     okl = frag.on && (frag.aux.y & 12) == 12 && (frag.aux.y & 3) != 0;    // tuple complete, neighbourhood valid, plane known
 #pragma unroll
                     for (int k = 0; k < 6; k++) {
-                        const float dx = sx - frag.mm[k].x, dy = sy - frag.mm[k].y, dz = sz - frag.mm[k].z;
-                        const float d2 = (dx * dx + dy * dy) + dz * dz;                 // L2_Simple order
-                        top6k_insert(t, (okl && k < nfr) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)frag.front[k]) : kKeyInf);
+                        float d2;
+                        const uint64_t key = make_key(frag.fr[k], sx, sy, sz, d2);       // L2_Simple order; low word: the member's map position
+                        top6k_insert(t, (okl && k < nfr) ? key : kKeyInf);
                     }
                     const float r = __int_as_float(frag.aux.w) - eps;                   // everything outside the six is at least this far away
                     const float d2_5 = __uint_as_float(key_hi(t.key[4]));
@@ -1613,8 +1416,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                             float x = 0.0f, y = 0.0f, z = 0.0f;
 #pragma unroll
                             for (int k = 0; k < 6; k++) {
-                                const bool is = k < nfr && frag.front[k] == (int)key_lo(t.key[j]);   // (rows beyond the member count hold stale positions)
-                                x = is ? frag.mm[k].x : x; y = is ? frag.mm[k].y : y; z = is ? frag.mm[k].z : z;
+                                const bool is = k < nfr && __float_as_int(frag.fr[k].w) == (int)key_lo(t.key[j]);   // (rows beyond the member count hold stale positions)
+                                x = is ? frag.fr[k].x : x; y = is ? frag.fr[k].y : y; z = is ? frag.fr[k].z : z;
                             }
                             qr[j][0] = x; qr[j][1] = y; qr[j][2] = z; mx[j][0] = x; mx[j][1] = y; mx[j][2] = z;
                         }
@@ -1652,7 +1455,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
             if (MODE == kCertify) {
                 defer = __ballot(need) != 0ull && !quick;                            // this workgroup's row is the search kernel's business
             } else if (HOOK || __builtin_expect(__ballot(need) != 0ull && !quick, 0)) {     // (unlikely: the search is laid out away from the certified path)
-                associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
+                associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                                       px, py, pz, cert, prof);
                 // The point is read again (L2-warm) rather than kept in registers through the association: what the
                 // certified path holds in registers must not be live across the search, or the allocator spills it on
@@ -1704,7 +1507,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                 cert = G((const v4f*)cp->cert)[i];
             }
         }
-        associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave], s_cand[wave],
+        associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                               px, py, pz, cert, prof);
     }
     }

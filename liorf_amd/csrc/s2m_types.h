@@ -13,7 +13,7 @@ constexpr int kFinThreads = 1024;      // finalize kernel workgroup
 constexpr int kMaxIter = 64;           // trace capacity
 constexpr int kProfWords = 32;         // uint64 words per wave written by the diagnostics variant of k_register
 constexpr int kBlocksQuantum = 8;      // graph cache key granularity (workgroups)
-constexpr int kNbrCap = 16;           // neighbourhood capacity per scan point (s2m_register.hpp: kNbr)
+constexpr int kNbrCap = 6;            // members of a scan point's front (s2m_register.hpp: kNbr)
 constexpr int kMaxBlocks = 512;        // largest k_register grid: two 8-wave workgroups on each of the 256 CUs, all co-resident
 constexpr int kBigWaves = 16;          // a scan that needs more than one 8-wave workgroup per CU runs 16-wave workgroups, one per CU: every
                                        // workgroup reads every row of partial sums when it closes an iteration, and rows x workgroups
@@ -61,10 +61,11 @@ struct DevCtx {
     // what a scan point remembers from launch to launch (see s2m_register.hpp); all reset by s2m_set_scan / s2m_set_map
     int32_t* npos;                // [5][n_q] its 5 neighbours, ascending (d2, map index), as positions in map_sorted
     float4*  cert;                // [n_q] {q_ref x,y,z: where the point stood when the tuple was established, slack: how far it may move}
-    int4*    aux;                 // [n_q] {r_out (float bits): every map point outside the neighbourhood was at least this far from q_ref,
+    int4*    aux;                 // [n_q] {r_out (float bits): every map point other than the front members was at least this far from q_ref,
                                   //        state: bits 0-1 plane 0 none / 1 passed the inlier test / 2 failed it, bit 2 the tuple is complete,
-                                  //        bit 3 the neighbourhood is valid, bit 4 plane_alt / npos_alt are valid, number of neighbourhood members, spare}
-    int32_t* nbr;                 // [kNbr][n_q] the neighbourhood: positions in map_sorted of EVERY map point within r_out of q_ref
+                                  //        bit 3 the front is valid, bit 4 plane_alt / npos_alt are valid, number of front members, r_out again}
+    float4*  front;               // [kNbr][n_q] the front: the (up to) six nearest map points the point knew when it last searched - EVERY map
+                                  //        point within r_out of q_ref - as {x, y, z, position in map_sorted (bits)}: re-measuring them needs no map access
     float4*  plane_cache;         // [n_q] pa,pb,pc,pd of the plane fitted to the tuple; pa = NaN: this point contributes nothing
     // the tuple (and its plane) a point had before its present one - state bit 4 says it is valid: two nearly equidistant
     // neighbours swap places back and forth with the micro-steps of the converged loop, and the plane of either order is kept
