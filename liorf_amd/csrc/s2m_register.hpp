@@ -63,6 +63,9 @@ constexpr int   kNbr = kNbrCap;        // members of a point's front: the six ne
 constexpr float kFragileSlack = 3e-5f; // a certificate with less slack than this may well fail in the steady state of the loop: such a lane prefetches
 constexpr float kSlabRound = 1e-6f;    // rounding of the cell binning per metre of distance from the grid origin (3 roundings of 6e-8 each, see kSlabMargin)
 constexpr float kAbsRound = 2.4e-7f;   // two ulps of an absolute coordinate, per metre of it
+constexpr int   kTilePad = 32;         // far-away entries behind a tile's last point (four steps of up to eight parts)
+constexpr int   kShareMin = 24;        // tile points from which idle lanes share the sweep of a pass with few searching lanes
+constexpr int   kServeLanes = 4;       // up to this many leftover lanes of a pass that cannot be staged are served one by one; more are split further
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));
 
@@ -372,7 +375,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
         const float rmax2 = wave_max_f32(act ? be2 : 0.0f);
         // (the filter box is compared in absolute coordinates: grown by their rounding as well)
         const float slabw = wave_max_f32(act ? slab + kAbsRound * (fabsf(sx) + fabsf(sy) + fabsf(sz)) : 0.0f);
-        const int tile_cap = kTilePts;
+        const int tile_cap = kTilePts - kTilePad;
         const float rr = sqrtf(rmax2) * 1.000001f + slabw;
         const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
         const bool few = nA <= cp->tune[3] && !(ablate & 128);      // a handful of lanes may be served one by one instead (experiments: S2M_TUNE)
@@ -452,8 +455,9 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 
         if (HOOK) prof.ts[1] = wall_clock64();
         if (!tile) {
-            // too dense or too scattered for one tile: again with half the lanes, or - 16 lanes or fewer - served one by one
-            if (!few && nA > 16 && !(ablate & 64)) { group = (nA > 32) ? 32 : 16; continue; }
+            // too dense or too scattered for one tile: again with fewer lanes (half, or the next power of two below), or - a
+            // handful of lanes - served one by one
+            if (!few && nA > kServeLanes && !(ablate & 64)) { group = (nA > 32) ? 32 : ((nA > 16) ? 16 : ((nA > 8) ? 8 : 4)); continue; }
             pend |= amask; todo &= ~amask;
             continue;
         }
@@ -466,23 +470,61 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
             // 2^-14 (18 um at 0.6 m); its distance part, the low bits cleared, is a LOWER bound of the point's true squared
             // distance.  Eight subtractions / multiplications / additions (packed: two tile points per instruction), one
             // v_and_or and seven v_med3 / v_min per lane and tile point, whatever the lane finds.
+            // Idle lanes join in: with nA <= 32 searching lanes, kq = 2, 4 or 8 lanes share one searching point - the wave is cut
+            // into kq parts of nslot = 64 / kq lanes, lane l works for slot l % nslot (the searching lane of that rank) and takes
+            // every kq-th tile point; the parts' lists are merged by a butterfly, and the searching lane of rank r picks its result
+            // up from lane r.  (The short waves of split chunks - 8, 16 or 32 points in a dense or a wide box - are the slowest
+            // waves of a first launch.)
+            nt = __builtin_amdgcn_readfirstlane(nt);
+            const int kq = (nA > 32 || nt < kShareMin) ? 1 : ((nA > 16) ? 2 : ((nA > 8) ? 4 : 8));
+            const int nslot = 64 / kq, part = lane / nslot;
+            int col = lane;                                   // the lane whose list is mine: my rank among the searching lanes
+            float qx_ = sx, qy_ = sy, qz_ = sz;
+            if (kq > 1) {
+                int* lown = reinterpret_cast<int*>(lrows);    // (the row table is not needed any more)
+                const int rank = __popcll(amask & ((1ull << lane) - 1ull));
+                if (act) lown[rank] = lane;
+                wave_lds_sync();
+                const int s_ = lane & (nslot - 1);
+                const int own = (s_ < nA) ? lown[s_] : lane;  // the searching lane this lane works for
+                col = act ? rank : lane;
+                qx_ = __shfl(sx, own, 64); qy_ = __shfl(sy, own, 64); qz_ = __shfl(sz, own, 64);
+            }
+            // behind the last tile point: entries far from everything, so that a step of four needs no bounds test
+            if (lane < kTilePad) lpts[nt + lane] = v4f{ 1.0e18f, 1.0e18f, 1.0e18f, 0.0f };
+            wave_lds_sync();
             uint32_t a[7];
 #pragma unroll
             for (int k = 0; k < 7; k++) a[k] = kNoKey;
             {
-                int j = 0;
-                for (; j + 2 <= nt; j += 2) {
-                    const v4f m0 = lpts[j], m1 = lpts[j + 1];
-                    float d0, d1;
-                    make_key(m0, sx, sy, sz, d0); make_key(m1, sx, sy, sz, d1);
-                    near7_insert(a, (__float_as_uint(d0) & ~kSlotMask) | (uint32_t)j);
-                    near7_insert(a, (__float_as_uint(d1) & ~kSlotMask) | (uint32_t)(j + 1));
+                // four tile points per step; the next step's reads are in flight behind this step's arithmetic
+                const v4f* lp = lpts + part;
+                int jv = part;
+                v4f m0 = lp[0], m1 = lp[kq], m2 = lp[2 * kq], m3 = lp[3 * kq];
+                for (int base = 0; base < nt; base += 4 * kq) {
+                    const v4f c0 = m0, c1 = m1, c2 = m2, c3 = m3;
+                    lp += 4 * kq;
+                    m0 = lp[0]; m1 = lp[kq]; m2 = lp[2 * kq]; m3 = lp[3 * kq];       // (at most 4 kq entries past the tile: the pad)
+                    float d0, d1, d2_, d3;
+                    make_key(c0, qx_, qy_, qz_, d0); make_key(c1, qx_, qy_, qz_, d1);
+                    make_key(c2, qx_, qy_, qz_, d2_); make_key(c3, qx_, qy_, qz_, d3);
+                    near7_insert(a, (__float_as_uint(d0) & ~kSlotMask) | (uint32_t)jv);
+                    near7_insert(a, (__float_as_uint(d1) & ~kSlotMask) | (uint32_t)(jv + kq));
+                    near7_insert(a, (__float_as_uint(d2_) & ~kSlotMask) | (uint32_t)(jv + 2 * kq));
+                    near7_insert(a, (__float_as_uint(d3) & ~kSlotMask) | (uint32_t)(jv + 3 * kq));
+                    jv += 4 * kq;
                 }
-                if (j < nt) {
-                    float d0;
-                    make_key(lpts[j], sx, sy, sz, d0);
-                    near7_insert(a, (__float_as_uint(d0) & ~kSlotMask) | (uint32_t)j);
-                }
+            }
+            for (int m = nslot; m < 64; m <<= 1) {            // merge the parts' lists
+                uint32_t o[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) o[k] = (uint32_t)__shfl_xor((int)a[k], m, 64);
+#pragma unroll
+                for (int k = 0; k < 7; k++) near7_insert(a, o[k]);
+            }
+            if (kq > 1) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) a[k] = (uint32_t)__shfl((int)a[k], col, 64);
             }
             // ---- the six nearest by key, measured exactly and put in exact order; beyond the reach nothing is known, so a
             // point farther than that is no member.  Every tile point other than the six has a key >= a[6]: its true squared
