@@ -247,3 +247,23 @@ def make_config(name: str, seed: int = SEED, scan_index: int = 0):
     return dict(map=m, scan=s, pose_gt=pose_gt, pose_init=pose_init_from(pose_gt),
                 meta=dict(name=name, sensor=sensor, n_q=n_q, n_m=n_m, leaf=leaf, seed=seed,
                           scan_index=scan_index))
+
+
+def move_config(cfg, yaw: float, t):
+    """The same scene somewhere else in the odometry frame: map points and poses under the rigid motion
+    p -> Rz(yaw) p + t (the reference's transformTobeMapped and local map live in the odometry / world frame and grow
+    without bound, src/mapOptmization.cpp:134,1273-1278); the scan stays in the lidar frame.  fp64 arithmetic, rounded
+    to fp32 once."""
+    c, s = np.cos(yaw), np.sin(yaw)
+    Rz = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    t = np.asarray(t, np.float64)
+    out = dict(cfg)
+    out["map"] = (cfg["map"].astype(np.float64) @ Rz.T + t).astype(np.float32)
+    for key in ("pose_gt", "pose_init"):
+        p = cfg[key].astype(np.float64)
+        q = p.copy()
+        q[2] = (p[2] + yaw + np.pi) % (2.0 * np.pi) - np.pi          # Rz(yaw) Rz(y) Ry(p) Rx(r): the yaw angles add
+        q[3:] = Rz @ p[3:] + t
+        out[key] = q.astype(np.float32)
+    out["meta"] = dict(cfg["meta"], moved=(float(yaw), [float(v) for v in t]))
+    return out
