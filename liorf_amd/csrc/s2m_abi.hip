@@ -853,7 +853,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->hctx.trace = reinterpret_cast<s2m_iter_trace*>(h->state.as<DevState>() + 1);
     params_to_ctx(h, prm);
     if (const char* e = getenv("S2M_ABLATE")) h->hctx.ablate = atoi(e);
-    h->hctx.tune[0] = 1 << 30; h->hctx.tune[1] = 1 << 30;
+    h->hctx.tune[0] = 1 << 30; h->hctx.tune[1] = 1 << 30; h->hctx.tune[2] = 0; h->hctx.tune[3] = 2;
     if (const char* e = getenv("S2M_TUNE")) { (void)sscanf(e, "%d,%d,%d,%d", &h->hctx.tune[0], &h->hctx.tune[1], &h->hctx.tune[2], &h->hctx.tune[3]); h->tune_env = true; }
     h->ctx_dirty = true;
     if (upload_ctx(h) != S2M_OK) return bail(S2M_ERR_HIP);
