@@ -28,6 +28,19 @@ namespace s2m {
 template <typename T> using gptr = __attribute__((address_space(1))) T*;
 template <typename T> __device__ __forceinline__ gptr<T> G(T* p) { return (gptr<T>)p; }
 typedef float v4f __attribute__((ext_vector_type(4)));
+// The DevCtx block of a scan is written by tiny kernels between the loops and only read by the registration kernels: seen
+// through the constant address space its fields - the buffer pointers above all - come by scalar loads into scalar
+// registers (a generic pointer makes every one of them a vector load into a pair of vector registers, because some store
+// of the kernel might alias it: sixteen registers per lane, and spills in the 128-register builds).
+typedef const __attribute__((address_space(4))) DevCtx* CtxP;
+__device__ __forceinline__ CtxP ctx_const(const DevCtx* p) { return (CtxP)p; }
+__device__ __forceinline__ GridDesc grid_of(CtxP cp)
+{
+    GridDesc g;
+    g.ox = cp->g.ox; g.oy = cp->g.oy; g.oz = cp->g.oz; g.inv_e = cp->g.inv_e; g.e = cp->g.e;
+    g.nx = cp->g.nx; g.ny = cp->g.ny; g.nz = cp->g.nz; g.ncells = cp->g.ncells;
+    return g;
+}
 __device__ __forceinline__ uint32_t f2ord(float f)
 {
     uint32_t u = __float_as_uint(f);
@@ -1142,7 +1155,7 @@ struct LmShared {
 // the last barrier (wave 0: after the solve; the other waves: at once, they would only wait there).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 template <int NT, bool kFull, typename Early = NoHook, typename Late = NoHook>
-__device__ __forceinline__ bool lm_close_iteration(const DevCtx* __restrict__ cp, gptr<DevState> st, int nb_act, int iter,
+__device__ __forceinline__ bool lm_close_iteration(CtxP cp, gptr<DevState> st, int nb_act, int iter,
                                                    bool writer, bool ne_only, const float (&pose0)[6], int degen0,
                                                    LmShared& sh, float* s_out, float (&pose_out)[6],
                                                    unsigned long long* stamps = nullptr,     // diagnostics: 5 wall-clock stamps
@@ -1325,7 +1338,7 @@ __device__ __forceinline__ void build_transform(const float (&pose)[6], int lane
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_wave_density(const SlotTable tbl, int raw_limit)
 {
-    const DevCtx* __restrict__ cp = tbl.ctx[blockIdx.y];
+    const CtxP cp = ctx_const(tbl.ctx[blockIdx.y]);
     const auto st = G((const DevState*)tbl.st[blockIdx.y]);
     const int lane = threadIdx.x & 63;
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1346,7 +1359,7 @@ __global__ __launch_bounds__(256) void k_wave_density(const SlotTable tbl, int r
     const float mny = wave_min_f32(fin ? sy : INFINITY), mxy = wave_max_f32(fin ? sy : -INFINITY);
     const float mnz = wave_min_f32(fin ? sz : INFINITY), mxz = wave_max_f32(fin ? sz : -INFINITY);
     if (!(mnx <= mxx)) return;
-    const GridDesc g = cp->g;
+    const GridDesc g = grid_of(cp);
     const auto cell_start = G(cp->cell_start);
     const int bx0 = max(cell_coord(mnx, g.ox, g.inv_e, g.nx) - 1, 0), bx1 = min(cell_coord(mxx, g.ox, g.inv_e, g.nx) + 1, g.nx - 1);
     const int by0 = max(cell_coord(mny, g.oy, g.inv_e, g.ny) - 1, 0), by1 = min(cell_coord(mxy, g.oy, g.inv_e, g.ny) + 1, g.ny - 1);
@@ -1374,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_wave_density(const SlotTable tbl, int r
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kFinThreads) void k_finalize(const SlotTable tbl, int iter, int mode)
 {
-    const DevCtx* __restrict__ cp = tbl.ctx[blockIdx.y];
+    const CtxP cp = ctx_const(tbl.ctx[blockIdx.y]);
     const auto st = G(tbl.st[blockIdx.y]);
     // loop state, fetched up front (the state block is a kernel argument: no pointer chase through DevCtx)
     const int done0 = st->done, degen0 = st->isDegenerate;

@@ -202,8 +202,11 @@ constexpr uint32_t kSlotMask = (1u << kSlotBits) - 1u;
 constexpr uint32_t kNoKey = 0xffffffffu;
 static_assert(kTilePts <= (1 << kSlotBits), "tile slots must fit the key's low bits");
 
-template <bool HOOK>
-__device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, const GridDesc& g, gptr<const v4f> map,
+// LEAN: the 128-register builds (two workgroups per CU: the scan slots of a batch, the 16-wave shape of large scans).  There a
+// pass stores its lanes' fronts straight from the tile and the plane fit fetches the five points again from the map
+// (L2-warm), instead of carrying 24 registers of coordinates through the passes that may follow.
+template <bool HOOK, bool LEAN>
+__device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr<const v4f> map,
                                                 gptr<const int32_t> cell_start, const float (&T)[12], float gatef, int ablate,
                                                 int2 chunk, int lane, v4f* lpts, int2* lrows,
                                                 float px, float py, float pz, v4f cert, WaveProf& prof)
@@ -280,6 +283,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 #pragma unroll
     for (int k = 0; k < 6; k++) nb[k] = v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
     bool have_nb = false;
+    bool front_done = false;                              // (LEAN) the pass has stored this lane's front already
 
     // ---- tier B: the front, measured at this pose (no memory access: its coordinates came with the state).  Everything
     // else is at least r_out - (distance moved since) away: if that is beyond the new 5th member the tuple is proved; if it
@@ -290,27 +294,24 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
     {
         const bool ev = need && nbr_ok && !(ablate & 2);
         if (__ballot(ev)) {
-            Top6k t;
-#pragma unroll
-            for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
+            // (measured straight into the outcome; a lane the front does not settle starts its search from an empty list again)
 #pragma unroll
             for (int k = 0; k < kNbr; k++) {
                 const bool on = ev && k < nb_n;
                 float d2;
                 const uint64_t key = make_key(fr[k], sx, sy, sz, d2);
-                top6k_insert(t, on ? key : kKeyInf);
+                top6k_insert(top, on ? key : kKeyInf);
             }
             const float r = r_out - eps;
-            const float d2_5 = __uint_as_float(key_hi(t.key[4]));
-            const bool have5 = key_hi(t.key[4]) < 0x7f800000u;
+            const float d2_5 = __uint_as_float(key_hi(top.key[4]));
+            const bool have5 = key_hi(top.key[4]) < 0x7f800000u;
             const bool in_gate = have5 && ((double)d2_5 < cp->gate_sq);
             const bool ok = in_gate ? (sqrtf(d2_5) + kCertMargin < r) : (gate_r + kCertMargin < r);
-            if (ev && ok) {
+            if (ev && ok) { rn = r; settled = true; }
+            else {
+                if (ev && have5 && !(ablate & 16)) { bound = fminf(d2_5, gatef); has_prior = true; }
 #pragma unroll
-                for (int q = 0; q < 6; q++) top.key[q] = t.key[q];
-                rn = r; settled = true;
-            } else if (ev && have5 && !(ablate & 16)) {
-                bound = fminf(d2_5, gatef); has_prior = true;
+                for (int q = 0; q < 6; q++) top.key[q] = kKeyInf;
             }
         }
         if (HOOK) prof.n_b += __popcll(__ballot(settled));
@@ -553,11 +554,12 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
                 for (int k = 0; k < 6; k++) {
                     const bool on = key_hi(t.key[k]) < 0x7f800000u;
                     const v4f m = lpts[on ? (int)key_lo(t.key[k]) : 0];
-                    nb[k] = on ? m : v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
                     top.key[k] = on ? (((uint64_t)key_hi(t.key[k]) << 32) | (uint32_t)__float_as_int(m.w)) : kKeyInf;
                     n6 += on ? 1 : 0;
+                    if (LEAN) { if (on) frontp[(size_t)k * nq + i] = m; }       // (a tile entry is a front entry: x, y, z, map position)
+                    else nb[k] = on ? m : v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
                 }
-                nb_n = n6; nbr_ok = true; settled = true; have_nb = true;
+                nb_n = n6; nbr_ok = true; settled = true; have_nb = !LEAN; front_done = LEAN;
                 rn = sqrtf(fminf(lb7, rim2)) * 0.999999f;
             }
             wave_lds_sync();                              // (the next pass stages into the same tile)
@@ -693,7 +695,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 #pragma unroll
     for (int k = 0; k < 5; k++) tie_adj = tie_adj || (key_hi(fk[k]) == key_hi(fk[k + 1]) && key_hi(fk[k]) < 0x7f800000u);
     tie_adj = tie_adj && upd;
-    const bool store_front = upd && searching && nbr_ok;  // a search's six become the point's front
+    const bool store_front = upd && searching && nbr_ok && !front_done;  // a search's six become the point's front
     // Coordinates + original indices of the six nearest from the map (L2-warm) - only where they are needed and not in hand:
     // the plane has to be fitted (new tuple, or a tuple that was not gated before) or the front stored by a lane that was not
     // settled from a tile, or equal distances have to be put in index order (the tile carries positions, not original
@@ -830,7 +832,7 @@ __device__ __forceinline__ void associate_chunk(const DevCtx* __restrict__ cp, c
 
 // residual, weight (:1125-1139) and Jacobian row (:1216-1234) of one point against its plane: keep = the point is a
 // correspondence (laserCloudOriFlag); cf = coeffSel; row / rhs = its line of matA / matB
-__device__ __forceinline__ bool linearise_row(const DevCtx* __restrict__ cp, const float (&T)[12], const float (&sc6)[6],
+__device__ __forceinline__ bool linearise_row(CtxP cp, const float (&T)[12], const float (&sc6)[6],
                                               float px, float py, float pz, const v4f pl, float (&cf)[4], float (&row)[6], float& rhs)
 {
     const float sx = ((T[0] * px + T[1] * py) + T[2]  * pz) + T[3];
@@ -873,7 +875,7 @@ __device__ __forceinline__ double line_product(const float (&row)[6], float rhs,
 // pass 2: residual, weight, Jacobian row and the 28 products of one wave-table entry (:1125-1139, :1216-1239)
 // ------------------------------------------------------------------------------------------
 template <bool HOOK>
-__device__ __forceinline__ void linearise_point(const DevCtx* __restrict__ cp, const float (&T)[12], const float (&sc6)[6],
+__device__ __forceinline__ void linearise_point(CtxP cp, const float (&T)[12], const float (&sc6)[6],
                                                 int i, float px, float py, float pz, const v4f pl, double (&acc)[kAcc])
 {
     float cf[4], row[6], rhs;
@@ -899,7 +901,7 @@ __device__ __forceinline__ void linearise_point(const DevCtx* __restrict__ cp, c
 }
 
 template <bool HOOK>
-__device__ __forceinline__ void linearise_chunk(const DevCtx* __restrict__ cp, const float (&T)[12], const float (&sc6)[6],
+__device__ __forceinline__ void linearise_chunk(CtxP cp, const float (&T)[12], const float (&sc6)[6],
                                                 int2 chunk, int lane, double (&acc)[kAcc])
 {
     const int i = chunk.x + lane;
@@ -1019,7 +1021,7 @@ __device__ __forceinline__ void wave_reduce_line(const float (&row)[6], float rh
 
 // the workgroup's partial row: the sums of its CNW waves, in wave order (after a barrier)
 template <int CNW>
-__device__ __forceinline__ void write_partial_row(const DevCtx* __restrict__ cp, int launch, int b, int tid, const double (*red)[32])
+__device__ __forceinline__ void write_partial_row(CtxP cp, int launch, int b, int tid, const double (*red)[32])
 {
     if (tid < kAcc) {
         const auto partial_row = G(cp->partials) + ((size_t)(launch & 1) * (size_t)cp->nblocks + b) * kAcc;   // slot launch & 1
@@ -1061,7 +1063,7 @@ __global__ __launch_bounds__(NW / EPW * 64, MINW) void k_certify_lean(const Slot
 {
     static_assert(NW % EPW == 0, "whole entries per wave");
     constexpr int NWL = NW / EPW;                              // waves of this workgroup
-    const DevCtx* __restrict__ cp = tbl.ctx[blockIdx.y];
+    const CtxP cp = ctx_const(tbl.ctx[blockIdx.y]);
     const auto st = G(tbl.st[blockIdx.y]);
     const int done = st->done, n_waves = st->n_waves;
     if (done) return;
@@ -1241,7 +1243,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     static_assert(MODE == kSearch || CNW == NW, "only the search kernel works on another kernel's partition");
     static_assert(CNW % NW == 0, "a search workgroup takes the waves of a row in whole rounds");
     static_assert(!(HOOK && MODE == kCertify), "the observation hook needs the association in line");
-    const DevCtx* __restrict__ cp = tbl.ctx[blockIdx.y];
+    const CtxP cp = ctx_const(tbl.ctx[blockIdx.y]);
     // The loop state block never moves, so it comes with the kernel arguments: `done` and the wave count arrive
     // with the first round trip, in parallel with the DevCtx block, instead of behind a pointer chase.
     const auto st = G(tbl.st[blockIdx.y]);
@@ -1292,7 +1294,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     const int estride = nb_act * CNW;
     const auto tb = G((const int2*)cp->wave_table);
     const int nq = cp->n_q;
-    const GridDesc g = cp->g;
+    const GridDesc g = grid_of(cp);
     const auto map = G((const v4f*)cp->map_sorted);
     const auto cell_start = G(cp->cell_start);
     const int ablate = cp->ablate;
@@ -1391,7 +1393,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                         cert = G((const v4f*)cp->cert)[i];
                     }
                 }
-                associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
+                associate_chunk<HOOK, (MINW > 2)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                                       px, py, pz, cert, prof);
             }
             if (HOOK) clk1 = wall_clock64();
@@ -1497,7 +1499,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
             if (MODE == kCertify) {
                 defer = __ballot(need) != 0ull && !quick;                            // this workgroup's row is the search kernel's business
             } else if (HOOK || __builtin_expect(__ballot(need) != 0ull && !quick, 0)) {     // (unlikely: the search is laid out away from the certified path)
-                associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
+                associate_chunk<HOOK, (MINW > 2)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                                       px, py, pz, cert, prof);
                 // The point is read again (L2-warm) rather than kept in registers through the association: what the
                 // certified path holds in registers must not be live across the search, or the allocator spills it on
@@ -1549,7 +1551,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                 cert = G((const v4f*)cp->cert)[i];
             }
         }
-        associate_chunk<HOOK>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
+        associate_chunk<HOOK, (MINW > 2)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                               px, py, pz, cert, prof);
     }
     }
