@@ -352,7 +352,6 @@ int scan_slot_prepare(s2m_context* h, const void* pts, size_t n, size_t stride, 
     h->hctx.wpb = wpb;
     // cutting a dense first-launch pass to 32 lanes pays in the 8-wave shape (kitti64: launch 0 89 -> 69 us); the 128-register
     // build of the 16-wave shape loses more to the extra passes than it gains (ouster128 160 -> 182 us, dense1m 318 -> 345 us)
-    if (!h->tune_env) { h->hctx.tune[0] = 1 << 30; h->hctx.tune[1] = 1 << 30; }
     h->hctx.nblocks = nblocks;
     h->hctx.table_cap = table_cap;
     h->ctx_dirty = true;
@@ -853,7 +852,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     h->hctx.trace = reinterpret_cast<s2m_iter_trace*>(h->state.as<DevState>() + 1);
     params_to_ctx(h, prm);
     if (const char* e = getenv("S2M_ABLATE")) h->hctx.ablate = atoi(e);
-    h->hctx.tune[0] = 1 << 30; h->hctx.tune[1] = 1 << 30; h->hctx.tune[2] = 0; h->hctx.tune[3] = 2;
+    h->hctx.tune[0] = 0; h->hctx.tune[1] = 0; h->hctx.tune[2] = 0; h->hctx.tune[3] = 2;
     if (const char* e = getenv("S2M_TUNE")) { (void)sscanf(e, "%d,%d,%d,%d", &h->hctx.tune[0], &h->hctx.tune[1], &h->hctx.tune[2], &h->hctx.tune[3]); h->tune_env = true; }
     h->ctx_dirty = true;
     if (upload_ctx(h) != S2M_OK) return bail(S2M_ERR_HIP);

@@ -65,6 +65,7 @@ constexpr float kSlabRound = 1e-6f;    // rounding of the cell binning per metre
 constexpr float kAbsRound = 2.4e-7f;   // two ulps of an absolute coordinate, per metre of it
 constexpr int   kTilePad = 32;         // far-away entries behind a tile's last point (four steps of up to eight parts)
 constexpr int   kShareMin = 24;        // tile points from which idle lanes share the sweep of a pass with few searching lanes
+constexpr int   kWalkPerLane = 6;      // a scattered wave's lanes walk their own cells if none has more candidates than this times the lanes to do
 constexpr int   kServeLanes = 4;       // up to this many leftover lanes of a pass that cannot be staged are served one by one; more are split further
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));
@@ -162,6 +163,62 @@ __device__ __forceinline__ void exact_top5_of_cells(gptr<const v4f> map, gptr<co
     }
 #pragma unroll
     for (int k = 0; k < 5; k++) out.key[k] = (ek[k] == kKeyInf) ? kKeyInf : (((uint64_t)key_hi(ek[k]) << 32) | (uint32_t)ep[k]);
+}
+
+// A lane's own search over its 3x3x3 cells, every lane of the wave for itself - for the lanes of a pass that are too far apart
+// to share a tile (a sparse far-field ring segment: consecutive points metres apart): all of them walk at once, each its <= 9
+// short runs, instead of being served one after the other.  Two steps, so that the wave can look at the candidate counts
+// before it commits: walk_runs sizes the runs (all eighteen cell_start reads in one round trip; the runs go to the lane's
+// column of `lruns`, [k][lane]) and returns the lane's candidate count; walk_top7 then measures them, four loads in flight,
+// and keeps the seven nearest as (d2 | position) keys, ascending.
+// `lim2`: rows / cells whose slab bound lies beyond it are skipped (every map point nearer than that is still met).
+__device__ __forceinline__ int walk_runs(gptr<const int32_t> cell_start, const GridDesc& g, int cx, int cy, int cz, float lim2,
+                                         float gx2m, float gx2p, float gy2m, float gy2p, float gz2m, float gz2p, int lane, int2* lruns)
+{
+    int P = 0;
+#pragma unroll 3
+    for (int k = 0; k < 9; k++) {
+        const int dyc = run_dy(k), dzc = run_dz(k);
+        const int yy = cy + dyc, zz = cz + dzc;
+        const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
+        int js = 0, je = 0;
+        if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > lim2)) {
+            const int xs = (cx > 0 && lb + gx2m <= lim2) ? cx - 1 : cx;
+            const int xe = (cx < g.nx - 1 && lb + gx2p <= lim2) ? cx + 1 : cx;
+            const int rb = (zz * g.ny + yy) * g.nx;
+            js = cell_start[rb + xs]; je = cell_start[rb + xe + 1];
+        }
+        lruns[k * 64 + lane] = make_int2(js, je);
+        P += je - js;
+    }
+    return P;
+}
+
+__device__ __forceinline__ void walk_top7(gptr<const v4f> map, float sx, float sy, float sz, int lane, const int2* lruns, uint64_t (&f)[7])
+{
+#pragma unroll
+    for (int k = 0; k < 7; k++) f[k] = kKeyInf | 0xffffffffull;
+#pragma unroll 1
+    for (int k = 0; k < 9; k++) {
+        const int2 r = lruns[k * 64 + lane];
+#pragma unroll 1
+        for (int j = r.x; j < r.y; j += 2) {
+            const bool two = j + 1 < r.y;
+            v4f m0 = map[j], m1 = map[two ? j + 1 : j];
+            m0.w = __int_as_float(j); m1.w = __int_as_float(j + 1);
+            float d0, d1;
+            const uint64_t k0 = make_key(m0, sx, sy, sz, d0);
+            const uint64_t k1 = two ? make_key(m1, sx, sy, sz, d1) : (kKeyInf | 0xffffffffull);
+            if (k0 < f[6] || k1 < f[6]) {
+                f[6] = (k0 < f[6]) ? k0 : f[6];
+#pragma unroll
+                for (int q = 6; q > 0; --q) cas_u64(f[q - 1], f[q]);
+                f[6] = (k1 < f[6]) ? k1 : f[6];
+#pragma unroll
+                for (int q = 6; q > 0; --q) cas_u64(f[q - 1], f[q]);
+            }
+        }
+    }
 }
 
 // per-wave diagnostics of the hook variant
@@ -356,9 +413,10 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
         // larger than the lanes' own neighbourhoods (scattered points) is not worth staging: those lanes are served one by one
         // below.  When the tile of a pass would overflow (a dense part of the map under a wide wave), the pass is repeated with
         // half the lanes - consecutive lanes are neighbours in space, so the box and with it the tile shrink.
-        unsigned long long todo = cmask, pend = 0ull;
+        unsigned long long todo = cmask, pend = 0ull, walk = 0ull;   // lanes to do in tile passes / to be served one by one / walking their own cells
         int group = 64;
         while (todo) {
+        if (HOOK) prof.cmax++;                            // (diagnostics: pass attempts)
         const bool act = ((todo >> lane) & 1ull) != 0ull && __popcll(todo & ((1ull << lane) - 1ull)) < group;
         const unsigned long long amask = __ballot(act);
         const int nA = __popcll(amask);
@@ -373,16 +431,118 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
         const int nyb = by1 - by0 + 1, nzb = bz1 - bz0 + 1;
         const int R = nyb * nzb;                          // rows in the box
         if (HOOK) { prof.rows = R; prof.why = 0; }
-        const float rmax2 = wave_max_f32(act ? be2 : 0.0f);
         // (the filter box is compared in absolute coordinates: grown by their rounding as well)
         const float slabw = wave_max_f32(act ? slab + kAbsRound * (fabsf(sx) + fabsf(sy) + fabsf(sz)) : 0.0f);
         const int tile_cap = kTilePts - kTilePad;
-        const float rr = sqrtf(rmax2) * 1.000001f + slabw;
+        const float be2p = be2, rim2p = rim2;             // this pass's reach (squared) and rim: the lanes' own
+        const float rr = sqrtf(wave_max_f32(act ? be2p : 0.0f)) * 1.000001f + slabw;
         const float fx0 = mnx - rr, fx1 = mxx + rr, fy0 = mny - rr, fy1 = mxy + rr, fz0 = mnz - rr, fz1 = mxz + rr;
         const bool few = nA <= cp->tune[3] && !(ablate & 128);      // a handful of lanes may be served one by one instead (experiments: S2M_TUNE)
         bool tile = !(ablate & 64) && !few && R <= kRowMax && (bx1 - bx0 + 1) * R <= 20 * max(nA, 8);
+        const bool scattered = !tile && !few && !(ablate & 64);
         if (HOOK && !tile) prof.why = 1;
         int nt = 0;                                       // tile fill, wave-uniform
+        // ---- the sweep of the tile as it stands: every lane keeps the seven nearest tile points by 32-bit keys - the bits of the
+        // squared distance with the low kSlotBits replaced by the tile slot.  Such a key orders two points correctly unless
+        // their distances agree to 2^-14 (18 um at 0.6 m); its distance part, the low bits cleared, is a LOWER bound of the
+        // point's true squared distance.  Eight subtractions / multiplications / additions, one v_and_or and seven v_med3 /
+        // v_min per lane and tile point, whatever the lane finds.
+        // Idle lanes join in (`share`): with nA <= 32 searching lanes, kq = 2, 4 or 8 lanes share one searching point - the wave is
+        // cut into kq parts of nslot = 64 / kq lanes, lane l works for slot l % nslot (the searching lane of that rank) and takes
+        // every kq-th tile point; the parts' lists are merged by a butterfly, and the searching lane of rank r picks its result
+        // up from lane r.  (The short waves of split chunks - 8, 16 or 32 points in a dense or a wide box - are the slowest
+        // waves of a first launch.)
+        auto sweep = [&](int ntile, bool share, uint32_t (&a)[7]) {
+            wave_lds_sync();
+            const int kq = (!share || nA > 32 || ntile < kShareMin) ? 1 : ((nA > 16) ? 2 : ((nA > 8) ? 4 : 8));
+            const int nslot = 64 / kq, part = lane / nslot;
+            int col = lane;                                   // the lane whose list is mine: my rank among the searching lanes
+            float qx_ = sx, qy_ = sy, qz_ = sz;
+            if (kq > 1) {
+                int* lown = reinterpret_cast<int*>(lrows);    // (the row table is not needed any more when `share` is set)
+                const int rank = __popcll(amask & ((1ull << lane) - 1ull));
+                if (act) lown[rank] = lane;
+                wave_lds_sync();
+                const int s_ = lane & (nslot - 1);
+                const int own = (s_ < nA) ? lown[s_] : lane;  // the searching lane this lane works for
+                col = act ? rank : lane;
+                qx_ = __shfl(sx, own, 64); qy_ = __shfl(sy, own, 64); qz_ = __shfl(sz, own, 64);
+            }
+            // behind the last tile point: entries far from everything, so that a step of four needs no bounds test
+            if (lane < kTilePad) lpts[ntile + lane] = v4f{ 1.0e18f, 1.0e18f, 1.0e18f, 0.0f };
+            wave_lds_sync();
+#pragma unroll
+            for (int k = 0; k < 7; k++) a[k] = kNoKey;
+            {
+                // four tile points per step; the next step's reads are in flight behind this step's arithmetic
+                const v4f* lp = lpts + part;
+                int jv = part;
+                v4f m0 = lp[0], m1 = lp[kq], m2 = lp[2 * kq], m3 = lp[3 * kq];
+                for (int base = 0; base < ntile; base += 4 * kq) {
+                    const v4f c0 = m0, c1 = m1, c2 = m2, c3 = m3;
+                    lp += 4 * kq;
+                    m0 = lp[0]; m1 = lp[kq]; m2 = lp[2 * kq]; m3 = lp[3 * kq];       // (at most 4 kq entries past the tile: the pad)
+                    float d0, d1, d2_, d3;
+                    make_key(c0, qx_, qy_, qz_, d0); make_key(c1, qx_, qy_, qz_, d1);
+                    make_key(c2, qx_, qy_, qz_, d2_); make_key(c3, qx_, qy_, qz_, d3);
+                    near7_insert(a, (__float_as_uint(d0) & ~kSlotMask) | (uint32_t)jv);
+                    near7_insert(a, (__float_as_uint(d1) & ~kSlotMask) | (uint32_t)(jv + kq));
+                    near7_insert(a, (__float_as_uint(d2_) & ~kSlotMask) | (uint32_t)(jv + 2 * kq));
+                    near7_insert(a, (__float_as_uint(d3) & ~kSlotMask) | (uint32_t)(jv + 3 * kq));
+                    jv += 4 * kq;
+                }
+            }
+            for (int m = nslot; m < 64; m <<= 1) {            // merge the parts' lists
+                uint32_t o[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++) o[k] = (uint32_t)__shfl_xor((int)a[k], m, 64);
+#pragma unroll
+                for (int k = 0; k < 7; k++) near7_insert(a, o[k]);
+            }
+            if (kq > 1) {
+#pragma unroll
+                for (int k = 0; k < 7; k++) a[k] = (uint32_t)__shfl((int)a[k], col, 64);
+            }
+        };
+        // ---- the six nearest by key, measured exactly and put in exact order (keys: distance bits | tile slot); beyond the
+        // reach nothing is known, so a point farther than that is no member.  Every tile point other than the six has a key
+        // >= a[6]: its true squared distance is at least a[6]'s distance part (returned).
+        auto exact_six = [&](const uint32_t (&a)[7], Top6k& t) -> float {
+#pragma unroll
+            for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const bool have = act && a[k] != kNoKey;
+                const int jk = have ? (int)(a[k] & kSlotMask) : 0;
+                float d2;
+                make_key(lpts[jk], sx, sy, sz, d2);
+                top6k_insert(t, (have && d2 <= rim2p) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)jk) : kKeyInf);
+            }
+            return (a[6] != kNoKey) ? __uint_as_float(a[6] & ~kSlotMask) : INFINITY;
+        };
+        // A box that holds more points than the tile: the tile is swept whenever it is full, its six go into the lane's running
+        // list (exact keys: distance | map position) and staging goes on into an empty tile.  `rest2` bounds everything seen
+        // that is not in the running list: what a sweep left outside its six, and what the list pushed out.
+        Top6k run;
+#pragma unroll
+        for (int k = 0; k < 6; k++) run.key[k] = kKeyInf;
+        float rest2 = INFINITY;
+        int nchunks = 0;
+        auto flush_chunk = [&](int ntile, bool share) {
+            uint32_t a[7];
+            sweep(ntile, share, a);
+            Top6k t;
+            rest2 = fminf(rest2, exact_six(a, t));
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                const bool on = key_hi(t.key[k]) < 0x7f800000u;
+                const v4f m = lpts[on ? (int)key_lo(t.key[k]) : 0];
+                const uint64_t out = top6k_insert(run, on ? (((uint64_t)key_hi(t.key[k]) << 32) | (uint32_t)__float_as_int(m.w)) : kKeyInf);
+                rest2 = fminf(rest2, __uint_as_float(min(key_hi(out), 0x7f800000u)));
+            }
+            nchunks++;
+            wave_lds_sync();                              // (staging goes on into the same tile)
+        };
         for (int rg = 0; rg < R && tile; rg += 64) {
             // each lane sets the bits of the (<= 9) box rows it still needs; one OR-reduce
             unsigned long long want = 0ull;
@@ -393,7 +553,7 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
                     const int yy = cy + dyc, zz = cz + dzc;
                     const float lb = (dyc < 0 ? gy2m : (dyc > 0 ? gy2p : 0.0f)) + (dzc < 0 ? gz2m : (dzc > 0 ? gz2p : 0.0f));
                     const int r = (zz - bz0) * nyb + (yy - by0) - rg;
-                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > be2) && r >= 0 && r < 64)
+                    if (yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz && !(lb > be2p) && r >= 0 && r < 64)
                         want |= 1ull << r;
                 }
             }
@@ -409,9 +569,6 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
             }
             const int ptot = __builtin_amdgcn_readlane(wave_incl_scan_i32(len), 63);
             if (HOOK) prof.raw += ptot;
-            if (ptot > kTileRaw) { tile = false; if (HOOK) prof.why = 2; break; }
-            // (experiments, S2M_TUNE: a dense box under a wide pass cut to 32 / 16 lanes - the sweep costs lanes x tile points)
-            if (((nA > 32 && ptot > cp->tune[0]) || (nA > 16 && nA <= 32 && ptot > cp->tune[1]))) { tile = false; if (HOOK) prof.why = 4; break; }
             // ---- stage through the filter: 16 lanes per row, 16 rows in flight per pass (four loads per lane); a point
             // enters the tile only if it lies inside the lanes' point box grown by the largest radius.
             // Rows nobody marked, and marked rows that are empty, are squeezed out first (through LDS): every
@@ -446,7 +603,12 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
                         const bool in = hv[u] && pv[u].x >= fx0 && pv[u].x <= fx1 && pv[u].y >= fy0 && pv[u].y <= fy1 && pv[u].z >= fz0 && pv[u].z <= fz1;
                         const unsigned long long mk = __ballot(in);
                         const int cn = __popcll(mk);
-                        if (nt + cn > tile_cap) { tile = false; if (HOOK) prof.why = 3; break; }
+                        if (nt + cn > tile_cap) {
+                            // the tile is full: sweep what it holds and go on into an empty one - or (128-register builds: no room for
+                            // a running list) give the pass up and take fewer lanes
+                            if (LEAN) { tile = false; if (HOOK) prof.why = 3; break; }
+                            flush_chunk(nt, false); nt = 0;
+                        }
                         if (in) lpts[nt + __popcll(mk & ((1ull << lane) - 1ull))] = pv[u];
                         nt += cn;
                     }
@@ -458,116 +620,74 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
         if (!tile) {
             // too dense or too scattered for one tile: again with fewer lanes (half, or the next power of two below), or - a
             // handful of lanes - served one by one
-            if (!few && nA > kServeLanes && !(ablate & 64)) { group = (nA > 32) ? 32 : ((nA > 16) ? 16 : ((nA > 8) ? 8 : 4)); continue; }
+            if (!few && nA > kServeLanes && !(ablate & 64)) {
+                if (scattered && group == 64) {
+                    // A box too wide for its lanes, at the first attempt.  Fewer lanes may share a pass (consecutive lanes are
+                    // neighbours) - but the lanes of a sparse far-field ring segment are metres apart one by one, and end up served
+                    // one after the other, 1.5 us each.  If every lane has few candidates in its own cells - fewer than serving
+                    // them would cost - they walk them below instead, every lane for itself and all at once.
+                    int2* lruns = reinterpret_cast<int2*>(lpts);
+                    const int P = walk_runs(cell_start, g, cx, cy, cz, be2, gx2m, gx2p, gy2m, gy2p, gz2m, gz2p, lane, lruns);
+                    wave_lds_sync();                      // (the tile area is the next pass's again)
+                    if (wave_max_i32(act ? P : 0) < kWalkPerLane * nA) { walk |= amask; todo &= ~amask; continue; }
+                }
+                group = (nA > 32) ? 32 : ((nA > 16) ? 16 : ((nA > 8) ? 8 : 4));
+                continue;
+            }
             pend |= amask; todo &= ~amask;
             continue;
         }
         todo &= ~amask;
         {
-            wave_lds_sync();
-            if (HOOK) { prof.mode = 1; prof.pts = nt; }
-            // ---- the sweep: every lane keeps the seven nearest tile points by 32-bit keys - the bits of the squared distance with
-            // the low kSlotBits replaced by the tile slot.  Such a key orders two points correctly unless their distances agree to
-            // 2^-14 (18 um at 0.6 m); its distance part, the low bits cleared, is a LOWER bound of the point's true squared
-            // distance.  Eight subtractions / multiplications / additions (packed: two tile points per instruction), one
-            // v_and_or and seven v_med3 / v_min per lane and tile point, whatever the lane finds.
-            // Idle lanes join in: with nA <= 32 searching lanes, kq = 2, 4 or 8 lanes share one searching point - the wave is cut
-            // into kq parts of nslot = 64 / kq lanes, lane l works for slot l % nslot (the searching lane of that rank) and takes
-            // every kq-th tile point; the parts' lists are merged by a butterfly, and the searching lane of rank r picks its result
-            // up from lane r.  (The short waves of split chunks - 8, 16 or 32 points in a dense or a wide box - are the slowest
-            // waves of a first launch.)
+            if (HOOK) { prof.mode = 1; prof.pts += nt; }
             nt = __builtin_amdgcn_readfirstlane(nt);
-            const int kq = (nA > 32 || nt < kShareMin) ? 1 : ((nA > 16) ? 2 : ((nA > 8) ? 4 : 8));
-            const int nslot = 64 / kq, part = lane / nslot;
-            int col = lane;                                   // the lane whose list is mine: my rank among the searching lanes
-            float qx_ = sx, qy_ = sy, qz_ = sz;
-            if (kq > 1) {
-                int* lown = reinterpret_cast<int*>(lrows);    // (the row table is not needed any more)
-                const int rank = __popcll(amask & ((1ull << lane) - 1ull));
-                if (act) lown[rank] = lane;
-                wave_lds_sync();
-                const int s_ = lane & (nslot - 1);
-                const int own = (s_ < nA) ? lown[s_] : lane;  // the searching lane this lane works for
-                col = act ? rank : lane;
-                qx_ = __shfl(sx, own, 64); qy_ = __shfl(sy, own, 64); qz_ = __shfl(sz, own, 64);
-            }
-            // behind the last tile point: entries far from everything, so that a step of four needs no bounds test
-            if (lane < kTilePad) lpts[nt + lane] = v4f{ 1.0e18f, 1.0e18f, 1.0e18f, 0.0f };
-            wave_lds_sync();
-            uint32_t a[7];
+            if (LEAN || __builtin_expect(nchunks == 0, 1)) {
+                // the whole box in one tile (nearly every pass)
+                uint32_t a[7];
+                sweep(nt, true, a);
+                Top6k t;
+                const float lb7 = exact_six(a, t);
+                // The answer stands if the exact 5th distance is below the bound of everything outside the six; otherwise (a
+                // near-tie the keys cannot resolve: rare) the lane is served exactly below.
+                const uint32_t h5 = key_hi(t.key[4]);
+                const bool sure = !(h5 < 0x7f800000u) || (__uint_as_float(h5) < lb7);
+                const unsigned long long unsure_m = __ballot(act && !sure);
+                pend |= unsure_m;
+                if (HOOK) prof.n_fb = __popcll(unsure_m);
+                if (act && sure) {
+                    int n6 = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) a[k] = kNoKey;
-            {
-                // four tile points per step; the next step's reads are in flight behind this step's arithmetic
-                const v4f* lp = lpts + part;
-                int jv = part;
-                v4f m0 = lp[0], m1 = lp[kq], m2 = lp[2 * kq], m3 = lp[3 * kq];
-                for (int base = 0; base < nt; base += 4 * kq) {
-                    const v4f c0 = m0, c1 = m1, c2 = m2, c3 = m3;
-                    lp += 4 * kq;
-                    m0 = lp[0]; m1 = lp[kq]; m2 = lp[2 * kq]; m3 = lp[3 * kq];       // (at most 4 kq entries past the tile: the pad)
-                    float d0, d1, d2_, d3;
-                    make_key(c0, qx_, qy_, qz_, d0); make_key(c1, qx_, qy_, qz_, d1);
-                    make_key(c2, qx_, qy_, qz_, d2_); make_key(c3, qx_, qy_, qz_, d3);
-                    near7_insert(a, (__float_as_uint(d0) & ~kSlotMask) | (uint32_t)jv);
-                    near7_insert(a, (__float_as_uint(d1) & ~kSlotMask) | (uint32_t)(jv + kq));
-                    near7_insert(a, (__float_as_uint(d2_) & ~kSlotMask) | (uint32_t)(jv + 2 * kq));
-                    near7_insert(a, (__float_as_uint(d3) & ~kSlotMask) | (uint32_t)(jv + 3 * kq));
-                    jv += 4 * kq;
+                    for (int k = 0; k < 6; k++) {
+                        const bool on = key_hi(t.key[k]) < 0x7f800000u;
+                        const v4f m = lpts[on ? (int)key_lo(t.key[k]) : 0];
+                        top.key[k] = on ? (((uint64_t)key_hi(t.key[k]) << 32) | (uint32_t)__float_as_int(m.w)) : kKeyInf;
+                        n6 += on ? 1 : 0;
+                        if (LEAN) { if (on) frontp[(size_t)k * nq + i] = m; }       // (a tile entry is a front entry: x, y, z, map position)
+                        else nb[k] = on ? m : v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+                    }
+                    nb_n = n6; nbr_ok = true; settled = true; have_nb = !LEAN; front_done = LEAN;
+                    rn = sqrtf(fminf(lb7, rim2p)) * 0.999999f;
                 }
-            }
-            for (int m = nslot; m < 64; m <<= 1) {            // merge the parts' lists
-                uint32_t o[7];
+            } else {
+                // the last tile of several: the running list holds the answer if its 5th is nearer than everything left outside
+                flush_chunk(nt, false);
+                const uint32_t h5 = key_hi(run.key[4]);
+                const bool sure = !(h5 < 0x7f800000u) || (__uint_as_float(h5) < rest2);
+                const unsigned long long unsure_m = __ballot(act && !sure);
+                pend |= unsure_m;
+                if (HOOK) prof.n_fb = __popcll(unsure_m);
+                if (act && sure) {
+                    int n6 = 0;
 #pragma unroll
-                for (int k = 0; k < 7; k++) o[k] = (uint32_t)__shfl_xor((int)a[k], m, 64);
-#pragma unroll
-                for (int k = 0; k < 7; k++) near7_insert(a, o[k]);
-            }
-            if (kq > 1) {
-#pragma unroll
-                for (int k = 0; k < 7; k++) a[k] = (uint32_t)__shfl((int)a[k], col, 64);
-            }
-            // ---- the six nearest by key, measured exactly and put in exact order; beyond the reach nothing is known, so a
-            // point farther than that is no member.  Every tile point other than the six has a key >= a[6]: its true squared
-            // distance is at least a[6]'s distance part.  The answer stands if the exact 5th distance is below that bound;
-            // otherwise (a near-tie the keys cannot resolve: rare) the lane is served exactly below.
-            Top6k t;
-#pragma unroll
-            for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                const bool have = act && a[k] != kNoKey;
-                const int jk = have ? (int)(a[k] & kSlotMask) : 0;
-                float d2;
-                make_key(lpts[jk], sx, sy, sz, d2);
-                top6k_insert(t, (have && d2 <= rim2) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)jk) : kKeyInf);
-            }
-            const float lb7 = (a[6] != kNoKey) ? __uint_as_float(a[6] & ~kSlotMask) : INFINITY;
-            const uint32_t h5 = key_hi(t.key[4]);
-            const bool sure = !(h5 < 0x7f800000u) || (__uint_as_float(h5) < lb7);
-            const unsigned long long unsure_m = __ballot(act && !sure);
-            pend |= unsure_m;
-            if (HOOK) prof.n_fb = __popcll(unsure_m);
-            if (act && sure) {
-                int n6 = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    const bool on = key_hi(t.key[k]) < 0x7f800000u;
-                    const v4f m = lpts[on ? (int)key_lo(t.key[k]) : 0];
-                    top.key[k] = on ? (((uint64_t)key_hi(t.key[k]) << 32) | (uint32_t)__float_as_int(m.w)) : kKeyInf;
-                    n6 += on ? 1 : 0;
-                    if (LEAN) { if (on) frontp[(size_t)k * nq + i] = m; }       // (a tile entry is a front entry: x, y, z, map position)
-                    else nb[k] = on ? m : v4f{ 0.0f, 0.0f, 0.0f, 0.0f };
+                    for (int k = 0; k < 6; k++) { top.key[k] = run.key[k]; n6 += (key_hi(run.key[k]) < 0x7f800000u) ? 1 : 0; }
+                    nb_n = n6; nbr_ok = true; settled = true; have_nb = false;       // (the coordinates come from the map again)
+                    rn = sqrtf(fminf(rest2, rim2p)) * 0.999999f;
                 }
-                nb_n = n6; nbr_ok = true; settled = true; have_nb = !LEAN; front_done = LEAN;
-                rn = sqrtf(fminf(lb7, rim2)) * 0.999999f;
             }
             wave_lds_sync();                              // (the next pass stages into the same tile)
         }
         }   // tile passes
         if (HOOK) prof.ts[2] = wall_clock64();
-        unsigned long long walk = 0ull;                   // lanes that walk their own cells (below)
-        if (__popcll(pend) > kWalkLanes) { walk = pend; pend = 0ull; }
         if (pend) {
             if (HOOK) prof.mode = (prof.why >= 2) ? 3 : 2;
             uint64_t* lkeys = reinterpret_cast<uint64_t*>(lpts);
@@ -644,19 +764,26 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
                 wave_lds_sync();                                  // the next lane's keys go to the same LDS area
             }
         }
-        // ---- lanes left to walk their own 3x3x3 cells (a tile that overflowed under many lanes, or more candidates than the
-        // served path holds): exact, slow, and without a front - the point searches again next launch
+        // ---- lanes that walk their own 3x3x3 cells, all at once: the lanes of passes too scattered to stage, and lanes with more
+        // candidates than the served path holds
         const bool walker = searching && ((walk >> lane) & 1ull) != 0ull;
         if (__ballot(walker)) {
             if (HOOK) prof.mode = 3;
+            int2* lruns = reinterpret_cast<int2*>(lpts);
+            (void)walk_runs(cell_start, g, cx, cy, cz, be2, gx2m, gx2p, gy2m, gy2p, gz2m, gz2p, lane, lruns);
             if (walker) {
-                Top5k best;
-                exact_top5_of_cells(map, cell_start, g, cx, cy, cz, sx, sy, sz, gatef, best);
+                uint64_t found[7];
+                walk_top7(map, sx, sy, sz, lane, lruns, found);
+                int n6 = 0;
 #pragma unroll
-                for (int k = 0; k < 5; k++) top.key[k] = best.key[k];
-                top.key[5] = kKeyInf;
-                rn = (best.key[4] != kKeyInf) ? sqrtf(__uint_as_float(key_hi(best.key[4]))) : gate_r;
-                settled = true; have_nb = false; nbr_ok = false;
+                for (int r = 0; r < 6; r++) {
+                    const bool have = key_hi(found[r]) < 0x7f800000u && __uint_as_float(key_hi(found[r])) <= rim2;
+                    top.key[r] = have ? found[r] : kKeyInf;
+                    n6 += have ? 1 : 0;
+                }
+                const bool seven = n6 == 6 && key_hi(found[6]) < 0x7f800000u;
+                rn = sqrtf(fminf(seven ? __uint_as_float(key_hi(found[6])) : INFINITY, rim2)) * 0.999999f;
+                nb_n = n6; nbr_ok = true; settled = true; have_nb = false;
             }
         }
         if (HOOK) prof.ts[3] = wall_clock64();
@@ -733,7 +860,9 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
         const float d2_5 = __uint_as_float(key_hi(fk[4]));
         const bool gated = complete && ((double)d2_5 < cp->gate_sq);                  // :1097
         v4f old_plane = { NAN, 0.0f, 0.0f, 0.0f };
-        if (complete && changed && had5 && (ost & 3) != 0 && !HOOK) old_plane = planep[i];   // the plane of the tuple the lane leaves
+        // (only a lane that re-measured: a lane that had to search moved far, and its old tuple is not coming back)
+        const bool leaves = complete && changed && had5 && (ost & 3) != 0 && !HOOK && !searching;
+        if (leaves) old_plane = planep[i];                                            // the plane of the tuple the lane leaves
         // The LS plane and its inlier test depend only on the ordered neighbour tuple, not on the pose: a point
         // that kept its tuple keeps its plane (and its verdict) bit for bit.
         int pst = (!changed && !(ablate & 32)) ? (ost & 3) : 0;
@@ -786,7 +915,7 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
         // places back and forth with the micro-steps of the converged loop, and the certify kernels exchange the two planes
         // instead of sending the lane here again.  (A kept pair stays valid whatever happens to the lane: a plane depends on
         // nothing but its tuple.)
-        const bool keep_old = complete && changed && had5 && (ost & 3) != 0 && !HOOK;
+        const bool keep_old = leaves;
         if (keep_old) {
             G((v4f*)cp->plane_alt)[i] = old_plane;
 #pragma unroll

@@ -93,7 +93,7 @@ struct DevCtx {
     double gate_sq, plane_tol, weight_scale, weight_min, conv_deg, conv_cm;
     float  eig_thresh;
     int32_t min_corr, max_iter, early_exit;
-    int32_t tune[4];              // experiments (env S2M_TUNE=a,b,c,d): [0] raw box points above which a pass of more than 32 lanes is cut to 32, [1] ... of more than 16 lanes to 16,
+    int32_t tune[4];              // experiments (env S2M_TUNE=a,b,c,d): [0]-[2] spare,
                                   // [3] a pass of up to this many searching lanes is served lane by lane instead of staging a tile (default 2)
     int32_t ablate;               // diagnostics and tests (env S2M_ABLATE): 1 no certificates (tier A off), 2 no re-measuring (tier B off), 16 ignore the stored tuple in the search, 32 ignore the plane cache, 64 gather path only, 128 tile path whatever the number of lanes
     // observation outputs of the hook variant (original scan order), may be null
