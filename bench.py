@@ -98,9 +98,32 @@ def rank_launch_command(n_gpus: int, argv: list[str], port: int | None = None) -
             "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def visible_gpu_count():
+    """GPUs this process could use, counted WITHOUT touching the HIP runtime (a process that has initialised the GPU must not
+    start other programs on this pool): the KFD topology nodes that have SIMDs, cut down by HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES when one of them is set.  None if the topology cannot be read (the ranks then find out themselves)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            try:
+                props = dict(line.split(None, 1) for line in open(os.path.join(base, node, "properties")).read().splitlines() if " " in line)
+            except OSError:
+                continue
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except OSError:
+        return 0 if not os.path.exists("/sys/class/kfd") else None      # no KFD at all: no AMD GPU driver, no GPU
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def start_ranks_if_asked(args, argv) -> None:
-    """`--gpus N` with N > 1 and no WORLD_SIZE: this process has made no GPU call yet (importing torch and counting devices make
-    none on this image), so it may start the N ranks as fresh child processes; it relays their output and exit code.  A rank
+    """`--gpus N` with N > 1 and no WORLD_SIZE: this process has made no GPU call (the devices are counted from sysfs, torch is
+    not even imported), so it may start the N ranks as fresh child processes; it relays their output and exit code.  A rank
     count that disagrees with --gpus is refused: silently running one rank and printing n_gpus: 1 was round 2's bug."""
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is not None:
@@ -114,9 +137,8 @@ def start_ranks_if_asked(args, argv) -> None:
     if args.print_launch:
         print(" ".join(cmd))
         raise SystemExit(0)
-    import torch
-    have = torch.cuda.device_count()                      # (no HIP initialisation: counting devices is not a GPU call here)
-    if have < args.gpus:
+    have = visible_gpu_count()                            # from sysfs: this process makes no HIP call at all before it starts the ranks
+    if have is not None and have < args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} asked for, {have} visible: refusing to run fewer ranks than asked for")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -128,6 +150,16 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
     start_ranks_if_asked(args, argv)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # One rank of several: a rank that fails must not leave its peers waiting in a collective it will never join.  It prints its
+        # error and leaves at once (no interpreter shutdown, no process-group destructor that could itself block); the launcher
+        # (torch.distributed.run) then ends the other ranks and returns non-zero, which the parent relays.
+        from liorf_amd import batch
+        return batch.run_rank(run, args)
+    return run(args)
+
+
+def run(args):
 
     # HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), round-robin in creation order; two
     # streams that land on one queue run strictly one after the other.  This process creates several engines (each with its
@@ -235,7 +267,7 @@ def main(argv=None):
     # stamped with a hash of liorf_amd/csrc), otherwise traffic is null and traffic_stale says why.
     traffic = traffic_raw = None
     traffic_stale = None
-    pmc_name = f"r03_k_register_pmc_{args.workload}.json"
+    pmc_name = f"r04_k_register_pmc_{args.workload}.json"
     pmc_file = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
@@ -249,7 +281,7 @@ def main(argv=None):
     # per-launch-index durations of the same command under rocprofv3 --kernel-trace (tools/launch_index_stats.py), if they
     # were taken on these kernel sources: the figure to trust for a single launch (no event packets around it)
     cold_rocprof_us = None
-    lis_file = os.path.join(ROOT, "profiles", f"r03_launch_index_stats_{args.workload}.json")
+    lis_file = os.path.join(ROOT, "profiles", f"r04_launch_index_stats_{args.workload}.json")
     if os.path.exists(lis_file):
         lis = json.load(open(lis_file))
         if lis.get("kernel_source_sha") == s2m.kernel_source_sha():
@@ -354,12 +386,14 @@ def main(argv=None):
             "workload": f"{args.workload}: {n_q}-pt scan vs {n_m}-pt local surf map, {max_iter} LM iterations per "
                         f"scan (early exit off), one scan per GPU at a time, {N_SCANS} distinct seeded scans in rotation, map replicated",
             "n_q": n_q, "n_m": n_m, "lm_iters_per_step": max_iter, "distinct_scans": N_SCANS,
-            "parallelism": f"scan-per-gpu x{world}" + (" + RCCL all_gather of 8-float records" if world > 1 else ""),
+            "parallelism": f"scan-per-gpu x{world}" + (" + RCCL all_gather of 8-float records, pipelined one step behind (the record of step k is exchanged while step k+1 runs)" if world > 1 else ""),
         },
         "roofline": {
             "bound": "hbm", "kernel": "k_register",
             "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK, 5), "traffic": traffic, "traffic_raw_counters": traffic_raw, "traffic_stale": traffic_stale,
+            # counter traffic over algorithmic bytes: wasted re-reads show here (null when the committed counters are not of these sources)
+            "traffic_ratio": (round(traffic / b_alg, 3) if traffic else None),
             "traffic_source": f"profiles/{pmc_name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                               "stamped with the hash of the kernel sources it was taken on)",
             "algorithmic_bytes_per_launch": b_alg, "kernel_us": round(kernel_ms * 1e3, 3),
@@ -373,7 +407,7 @@ def main(argv=None):
             "frac": round(achieved_cold / HBM_PEAK, 5), "algorithmic_bytes_per_launch": b_alg,
             "kernel_us": round(cold_ms * 1e3, 2), "kernel_us_source": "HIP event pair around launch 0, mean of 10 loops (live)",
             "kernel_us_rocprof": cold_rocprof_us,
-            "kernel_us_rocprof_source": f"profiles/r03_launch_index_stats_{args.workload}.json (rocprofv3 --kernel-trace of this "
+            "kernel_us_rocprof_source": f"profiles/r04_launch_index_stats_{args.workload}.json (rocprofv3 --kernel-trace of this "
                                         "command, dispatches numbered inside their loop; null unless taken on the running sources)",
         },
         "ms_per_step_windows": {"min": round(min(windows), 4), "median": round(float(np.median(windows)), 4), "max": round(max(windows), 4), "n": len(windows)},
@@ -385,6 +419,9 @@ def main(argv=None):
         "points_per_s_loop_mean": round(n_q / (kernel_ms * 1e-3), 1),
         "device_ms_per_step": round(device_ms, 4),
         "map_index_build_ms": round(tm["set_map_ms"], 4),
+        # "map index build reported separately and also amortised" - the reference rebuilds its kd-tree for
+        # every scan (:1302); with the device index build charged to every step:
+        "value_with_map_index_build": round(world * max_iter * 1e3 / (ms_per_step + tm["set_map_ms"]), 1),
         "scan_prep_ms": round(tm["set_scan_ms"], 4),
         "last_result": {"iters_run": r.iters_run, "converged": r.converged, "n_sel": r.n_sel_last, "scan_index": k_last,
                         "pose_err_m": float(np.abs(np.array(r.pose)[3:] - cfgs[k_last]["pose_gt"][3:]).max())},

@@ -13,6 +13,25 @@ import torch.distributed as dist
 RECORD_FLOATS = 8
 
 
+def run_rank(fn, *args, **kwargs):
+    """Run one rank's work so that a failure cannot leave its peers waiting in a collective it will never join: the error is
+    printed and the process leaves at once with code 1 - no interpreter shutdown, no process-group destructor that could itself
+    block on the peers.  The launcher (torch.distributed.run) then ends the other ranks and returns non-zero.  SystemExit passes
+    through (a deliberate exit code)."""
+    import os
+    import sys
+    import traceback
+    try:
+        return fn(*args, **kwargs)
+    except SystemExit:
+        raise
+    except BaseException:
+        traceback.print_exc()
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)
+
+
 def shard_scans(n_scans: int, world: int, rank: int) -> list[int]:
     """Round-robin assignment of scan indices to ranks (scan i -> rank i % world)."""
     if not (0 <= rank < world):

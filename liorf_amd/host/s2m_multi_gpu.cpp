@@ -15,6 +15,11 @@
 //     early_exit    1 (default): the loop breaks on convergence as the reference does (:1313); 0: all 30 iterations (the bench's step)
 //     map.bin       local surf map, pcl::PointXYZI records (32-byte stride)
 //     manifest.txt  one scan per line:  scan.bin roll pitch yaw x y z      (initial guess = transformTobeMapped)
+//   A worker that fails (a library or HIP error in its shard) reports it at a host-side agreement point in front of the
+//   collective: every worker then skips the all-gather together, and the program prints the error and exits non-zero - no
+//   rank is left waiting in a collective its peer never joins.  A worker that does not come back at all (a collective that
+//   never completes) is given up after S2M_MULTI_GPU_TIMEOUT_S seconds (default 120): the communicators are aborted and the
+//   process exits with code 3.
 //   prints one line per scan: "scan <i> dev <d> iters <n> n_sel <m> pose r p y x y z" (read back from the gathered table of
 //   device 0), and "gpus G scans S reps R seconds_per_batch T seconds_per_scan T/S" - T the median over `reps` timed batches
 //   behind one untimed warm-up batch, setup excluded.
@@ -82,14 +87,27 @@ struct Rank {
 // the batches: the main thread raises `generation`, every worker runs one batch and reports
 struct Gate {
     std::mutex m;
-    std::condition_variable go, done;
+    std::condition_variable go, done, agree;
     long generation = 0;
     int finished = 0;
     bool quit = false;
+    // the agreement point in front of the collective: every worker reports whether its shard went through; the last to arrive
+    // releases the others, and they all see the same verdict
+    int n = 1, arrived = 0, failed = 0;
+    long phase = 0;
 };
 
-void run_batch(Rank& r)
+// test hook: S2M_MULTI_GPU_FAIL_RANK=<device> makes that device's worker fail in its second batch (the first timed one)
+int fail_rank()
 {
+    const char* e = std::getenv("S2M_MULTI_GPU_FAIL_RANK");
+    return e ? std::atoi(e) : -1;
+}
+
+// the registrations of this device's shard (may throw)
+void register_shard(Rank& r, long batch_no)
+{
+    if (batch_no >= 2 && r.dev == fail_rank()) throw std::runtime_error("S2M_MULTI_GPU_FAIL_RANK: injected failure");
     const int n_mine = (int)r.mine.size();
     std::copy(r.poses_in.begin(), r.poses_in.end(), r.poses.begin());
     for (int k = 0; k < kRecord * r.per_rank; k++) r.h_send[k] = NAN;
@@ -110,6 +128,11 @@ void run_batch(Rank& r)
         rec[6] = (float)r.results[(size_t)k].iters_run;
         rec[7] = (float)r.results[(size_t)k].n_sel_last;
     }
+}
+
+// the one collective of the batch (entered by every worker or by none)
+void gather_records(Rank& r)
+{
     CHECK_HIP(hipMemcpyAsync(r.d_send, r.h_send, sizeof(float) * kRecord * (size_t)r.per_rank, hipMemcpyHostToDevice, r.stream));
     // the one collective of the batch: all-gather of the records over RCCL (xGMI between the GPUs of a node), on this device's stream
     CHECK_NCCL(ncclAllGather(r.d_send, r.d_recv, (size_t)kRecord * (size_t)r.per_rank, ncclFloat, r.comm, r.stream));
@@ -128,9 +151,22 @@ void worker(Rank* rp, Gate* g)
             if (g->quit) return;
             seen = g->generation;
         }
-        if (r.error.empty()) {
-            try { run_batch(r); } catch (const std::exception& e) { r.error = e.what(); }
+        bool ok = r.error.empty();
+        if (ok) {
+            try { register_shard(r, seen); } catch (const std::exception& e) { r.error = e.what(); ok = false; }
         }
+        bool all_ok = false;
+        {   // agreement: nobody enters the all-gather unless everybody can
+            std::unique_lock<std::mutex> lk(g->m);
+            if (!ok) g->failed++;
+            if (++g->arrived == g->n) { g->phase++; g->agree.notify_all(); }
+            else { const long p = g->phase; g->agree.wait(lk, [&] { return g->phase != p; }); }
+            all_ok = g->failed == 0;
+        }
+        if (all_ok) {
+            try { gather_records(r); } catch (const std::exception& e) { r.error = e.what(); }
+        } else if (r.error.empty())
+            r.error = "skipped the all-gather: another device failed";
         {
             std::lock_guard<std::mutex> lk(g->m);
             g->finished++;
@@ -208,7 +244,19 @@ int main(int argc, char** argv)
             CHECK_HIP(hipMalloc((void**)&r.d_recv, sizeof(float) * kRecord * (size_t)per_rank * (size_t)n));
         }
         Gate gate;
+        gate.n = n;
+        const double timeout_s = std::getenv("S2M_MULTI_GPU_TIMEOUT_S") ? std::atof(std::getenv("S2M_MULTI_GPU_TIMEOUT_S")) : 120.0;
         for (int d = 0; d < n; d++) ranks[(size_t)d].thread = std::thread(worker, &ranks[(size_t)d], &gate);
+        // (whatever happens below, the workers are told to quit and joined before `ranks` goes away: a joinable std::thread
+        // destroyed during stack unwinding would end the process in std::terminate instead of with the error message)
+        auto stop_workers = [&]() {
+            {
+                std::lock_guard<std::mutex> lk(gate.m);
+                gate.quit = true;
+            }
+            gate.go.notify_all();
+            for (Rank& r : ranks) if (r.thread.joinable()) r.thread.join();
+        };
 
         auto one_batch = [&]() {
             const auto t0 = std::chrono::steady_clock::now();
@@ -220,15 +268,43 @@ int main(int argc, char** argv)
             gate.go.notify_all();
             {
                 std::unique_lock<std::mutex> lk(gate.m);
-                gate.done.wait(lk, [&] { return gate.finished == n; });
+                if (!gate.done.wait_for(lk, std::chrono::duration<double>(timeout_s), [&] { return gate.finished == n; })) {
+                    // a worker is stuck (in a collective that will never complete, or on a device that hangs): nothing to join
+                    lk.unlock();
+                    std::fprintf(stderr, "s2m_multi_gpu: %d of %d devices did not finish a batch within %.0f s - aborting the communicators\n",
+                                 n - gate.finished, n, timeout_s);
+                    for (ncclComm_t c : comms) (void)ncclCommAbort(c);
+                    std::fflush(stderr);
+                    std::_Exit(3);
+                }
             }
             const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            for (const Rank& r : ranks) if (!r.error.empty()) throw std::runtime_error("device " + std::to_string(r.dev) + ": " + r.error);
+            std::string first;                           // the error of the device that failed, not of those that stood by
+            for (const Rank& r : ranks)
+                if (!r.error.empty() && r.error.rfind("skipped", 0) != 0 && first.empty()) first = "device " + std::to_string(r.dev) + ": " + r.error;
+            for (const Rank& r : ranks)
+                if (!r.error.empty() && first.empty()) first = "device " + std::to_string(r.dev) + ": " + r.error;
+            if (!first.empty()) throw std::runtime_error(first);
             return s;
         };
-        one_batch();                                         // warm-up: buffers sized, graphs captured, RCCL channels up
         std::vector<double> times;
-        for (int rep = 0; rep < reps; rep++) times.push_back(one_batch());
+        try {
+            {
+                std::lock_guard<std::mutex> lk(gate.m);
+                gate.arrived = 0; gate.failed = 0;
+            }
+            one_batch();                                     // warm-up: buffers sized, graphs captured, RCCL channels up
+            for (int rep = 0; rep < reps; rep++) {
+                {
+                    std::lock_guard<std::mutex> lk(gate.m);
+                    gate.arrived = 0; gate.failed = 0;
+                }
+                times.push_back(one_batch());
+            }
+        } catch (...) {
+            stop_workers();
+            throw;
+        }
         std::sort(times.begin(), times.end());
         const double t_batch = times[times.size() / 2];
 
@@ -248,12 +324,7 @@ int main(int argc, char** argv)
         }
         std::printf("gpus %d scans %d reps %d seconds_per_batch %.6f seconds_per_scan %.6f\n", n, n_scans, reps, t_batch, t_batch / n_scans);
 
-        {
-            std::lock_guard<std::mutex> lk(gate.m);
-            gate.quit = true;
-        }
-        gate.go.notify_all();
-        for (Rank& r : ranks) r.thread.join();
+        stop_workers();
         for (int d = 0; d < n; d++) {
             Rank& r = ranks[(size_t)d];
             (void)hipSetDevice(d);

@@ -71,3 +71,22 @@ def test_shard_is_a_partition():
 def test_single_process_path_needs_no_group():
     recs = np.stack([batch.pack_record(np.arange(6) + s, s, s) for s in range(3)])
     assert np.array_equal(batch.gather_records(recs, 3), recs)
+
+
+def test_a_failing_rank_ends_the_job_nonzero_and_promptly():
+    """Round-3 verdict item 5: rank 1 raises before the all-gather rank 0 is already waiting in.  With batch.run_rank (what
+    bench.py wraps every rank in) the failing rank leaves at once, the launcher ends its peer, and the job returns non-zero
+    well inside 30 s - nobody is left in a collective."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = os.path.join(root, "tests", "tools", "rank_failure_prog.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(_free_port()), prog], capture_output=True, text=True, timeout=120, env=env)
+    took = time.time() - t0
+    assert out.returncode != 0, out.stdout[-500:]
+    assert "injected failure" in out.stderr and "gathered" not in out.stdout
+    assert took < 30.0, took

@@ -28,9 +28,11 @@ def test_gpus_2_yields_a_two_rank_launch_command():
 
 
 def test_gpus_2_without_two_gpus_fails_loudly():
-    import torch
-    if torch.cuda.device_count() >= 2:
-        pytest.skip("two GPUs present")
+    sys.path.insert(0, ROOT)
+    import bench
+    have = bench.visible_gpu_count()
+    if have is None or have >= 2:
+        pytest.skip("two GPUs present, or no KFD topology to count them from")
     out = _run(["--gpus", "2", "--steps", "1", "--warmup", "0"])
     assert out.returncode != 0
     assert "--gpus 2" in out.stderr and "visible" in out.stderr
@@ -50,10 +52,10 @@ def test_launch_command_helper_is_importable_without_side_effects():
 
 
 def test_committed_bench_line_of_this_round():
-    """profiles/r03_bench_line.json is what `python bench.py` printed on the MI355X this round."""
-    path = os.path.join(ROOT, "profiles", "r03_bench_line.json")
+    """profiles/r04_bench_line.json is what `python bench.py` printed on the MI355X this round."""
+    path = os.path.join(ROOT, "profiles", "r04_bench_line.json")
     if not os.path.exists(path):
-        pytest.skip("no r03 bench line committed yet")
+        pytest.skip("no r04 bench line committed yet")
     d = json.loads(open(path).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "roofline_cold", "cpu_baseline"):
@@ -76,3 +78,10 @@ def test_committed_bench_line_of_this_round():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 4 and c["unit"] == d["unit"] and "early_exit" in c
     assert abs(d["value"] - d["config"]["lm_iters_per_step"] * 1e3 / d["ms_per_step"]) / d["value"] < 1e-3
+    # the figure with the map index build charged to every scan, beside `value`
+    want = d["config"]["lm_iters_per_step"] * 1e3 / (d["ms_per_step"] + d["map_index_build_ms"])
+    assert abs(d["value_with_map_index_build"] - want) / want < 2e-3 and d["value_with_map_index_build"] < d["value"]
+    assert "traffic_ratio" in d["roofline"]
+    if d["roofline"]["traffic"] is not None:
+        assert abs(d["roofline"]["traffic_ratio"] - d["roofline"]["traffic"] / d["roofline"]["algorithmic_bytes_per_launch"]) < 2e-3
+    assert "chain" in d and set(("extract_cloud_ms", "downsample_scan_ms", "optimize_ms")) <= set(d["chain"])
