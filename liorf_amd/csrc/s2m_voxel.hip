@@ -28,6 +28,7 @@ struct VoxSetup {
     int32_t  leaf_too_small;
     int32_t  n_valid;
     int32_t  n_out;
+    int32_t  n_long;                                 // voxels with a long run of points, handed to k_vox_centroid_long
     uint32_t mm[6];                                  // ordered-uint min xyz, max xyz
 };
 
@@ -60,7 +61,7 @@ __global__ void k_vox_reset(VoxSetup* s)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         for (int d = 0; d < 3; d++) { s->mm[d] = 0xffffffffu; s->mm[3 + d] = 0u; }
-        s->n_valid = 0; s->n_out = 0; s->leaf_too_small = 0;
+        s->n_valid = 0; s->n_out = 0; s->leaf_too_small = 0; s->n_long = 0;
     }
 }
 
@@ -166,9 +167,21 @@ __global__ __launch_bounds__(256) void k_vox_heads(const uint32_t* __restrict__ 
 }
 
 // One lane per voxel: CentroidPoint<PointXYZI> over the run [heads[v], heads[v+1]) in sorted order.
+constexpr int kLongRun = 96;          // a voxel with more points than this is summed by a whole wave (k_vox_centroid_long)
+
+__device__ __forceinline__ void write_centroid(unsigned char* __restrict__ out, size_t out_stride, int v, float sx, float sy, float sz, float si, float cnt)
+{
+    float* o = reinterpret_cast<float*>(out + (size_t)v * out_stride);
+    o[0] = sx / cnt; o[1] = sy / cnt; o[2] = sz / cnt;
+    const int words = (int)(out_stride >> 2);
+    if (words > 3) o[3] = 1.0f;
+    if (words > 4) o[4] = si / cnt;
+    for (int k = 5; k < words; k++) o[k] = 0.0f;
+}
+
 __global__ __launch_bounds__(256) void k_vox_centroid(const unsigned char* __restrict__ pts, size_t stride,
                                                       const int32_t* __restrict__ vals, const int32_t* __restrict__ heads,
-                                                      const VoxSetup* __restrict__ s, unsigned char* __restrict__ out,
+                                                      VoxSetup* __restrict__ s, int32_t* __restrict__ long_list, unsigned char* __restrict__ out,
                                                       size_t out_stride, int cap)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -176,19 +189,87 @@ __global__ __launch_bounds__(256) void k_vox_centroid(const unsigned char* __res
     if (v >= n_out || v >= cap) return;
     const int first = heads[v];
     const int last = (v + 1 < n_out) ? heads[v + 1] : s->n_valid;
+    if (last - first > kLongRun) { long_list[atomicAdd(&s->n_long, 1)] = v; return; }   // (order of the list does not matter: a voxel, an output record)
     float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
-    for (int j = first; j < last; j++) {
+    // The sums are sequential by definition (fp32, ascending point index: the oracle's order), the loads are not: eight points'
+    // records are requested at once and added one after the other (a lane walking its run one dependent gather at a time was 60 %
+    // of extractCloud: 21 points per voxel on average, hundreds where key frames overlap).
+    const bool has_i = stride >= 20;
+    int j = first;
+    for (; j + 8 <= last; j += 8) {
+        int id[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) id[u] = vals[j + u];
+        float x[8], y[8], z[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const float* p = reinterpret_cast<const float*>(pts + (size_t)id[u] * stride);
+            x[u] = p[0]; y[u] = p[1]; z[u] = p[2]; w[u] = has_i ? p[4] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) { sx += x[u]; sy += y[u]; sz += z[u]; si += w[u]; }
+    }
+    for (; j < last; j++) {
         const float* p = reinterpret_cast<const float*>(pts + (size_t)vals[j] * stride);
         sx += p[0]; sy += p[1]; sz += p[2];
-        if (stride >= 20) si += p[4];
+        if (has_i) si += p[4];
     }
-    const float cnt = (float)(last - first);
-    float* o = reinterpret_cast<float*>(out + (size_t)v * out_stride);
-    o[0] = sx / cnt; o[1] = sy / cnt; o[2] = sz / cnt;
-    const int words = (int)(out_stride >> 2);
-    if (words > 3) o[3] = 1.0f;
-    if (words > 4) o[4] = si / cnt;
-    for (int k = 5; k < words; k++) o[k] = 0.0f;
+    write_centroid(out, out_stride, v, sx, sy, sz, si, (float)(last - first));
+}
+
+// The long runs (a voxel where many key frames overlap holds hundreds of points; one near the sensor thousands): a wave per
+// voxel.  64 records at a time are gathered by the 64 lanes (one round trip) into LDS, and lanes 0..3 each add up one
+// component - x, y, z, intensity - point after point in the run's order: the same sequential fp32 sums as a single lane
+// would form, without 64 dependent gathers in a row.
+__global__ __launch_bounds__(256) void k_vox_centroid_long(const unsigned char* __restrict__ pts, size_t stride,
+                                                           const int32_t* __restrict__ vals, const int32_t* __restrict__ heads,
+                                                           const VoxSetup* __restrict__ s, const int32_t* __restrict__ long_list,
+                                                           unsigned char* __restrict__ out, size_t out_stride)
+{
+    constexpr int kChunk = 256;                      // records per round trip: four per lane
+    __shared__ float comp[4][4][kChunk];             // [wave][component][point of the chunk]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n_long = s->n_long, n_out = s->n_out, n_valid = s->n_valid;
+    const bool has_i = stride >= 20;
+    auto lds_sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    for (int item = blockIdx.x * 4 + wave; item < n_long; item += gridDim.x * 4) {
+        const int v = long_list[item];
+        const int first = heads[v];
+        const int last = (v + 1 < n_out) ? heads[v + 1] : n_valid;
+        float sum = 0.0f;                             // lanes 0..3: the running sum of component `lane`
+        float rx[4], ry[4], rz[4], rw[4];
+        auto fetch = [&](int c) {                     // this lane's four records of the chunk that starts at c
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = c + 64 * u + lane;
+                rx[u] = ry[u] = rz[u] = rw[u] = 0.0f;
+                if (j < last) {
+                    const float* p = reinterpret_cast<const float*>(pts + (size_t)vals[j] * stride);
+                    rx[u] = p[0]; ry[u] = p[1]; rz[u] = p[2]; rw[u] = has_i ? p[4] : 0.0f;
+                }
+            }
+        };
+        fetch(first);
+        for (int c = first; c < last; c += kChunk) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                comp[wave][0][64 * u + lane] = rx[u]; comp[wave][1][64 * u + lane] = ry[u];
+                comp[wave][2][64 * u + lane] = rz[u]; comp[wave][3][64 * u + lane] = rw[u];
+            }
+            lds_sync();
+            if (c + kChunk < last) fetch(c + kChunk);    // the next chunk's gathers are in flight behind this chunk's sums
+            const int m = min(kChunk, last - c);
+            if (lane < 4) {
+                const float* col = comp[wave][lane];
+                int k = 0;
+                for (; k + 4 <= m; k += 4) { sum += col[k]; sum += col[k + 1]; sum += col[k + 2]; sum += col[k + 3]; }
+                for (; k < m; k++) sum += col[k];
+            }
+            lds_sync();
+        }
+        const float sx = __shfl(sum, 0, 64), sy = __shfl(sum, 1, 64), sz = __shfl(sum, 2, 64), si = __shfl(sum, 3, 64);
+        if (lane == 0) write_centroid(out, out_stride, v, sx, sy, sz, si, (float)(last - first));
+    }
 }
 
 __global__ __launch_bounds__(256) void k_copy_records(const unsigned char* __restrict__ in, size_t stride, int n,
@@ -232,7 +313,7 @@ __global__ __launch_bounds__(256) void k_transform_frames(const unsigned char* c
 }  // namespace
 
 struct VoxWorkspace {
-    Buf setup, keys_a, keys_b, vals_a, vals_b, flags, heads, cub_tmp, frame_tab;
+    Buf setup, keys_a, keys_b, vals_a, vals_b, flags, heads, cub_tmp, frame_tab, long_list;
     VoxSetup* h_setup = nullptr;          // pinned
 };
 
@@ -248,7 +329,7 @@ VoxWorkspace* vox_create()
 void vox_destroy(VoxWorkspace* w)
 {
     if (!w) return;
-    Buf* bufs[] = { &w->setup, &w->keys_a, &w->keys_b, &w->vals_a, &w->vals_b, &w->flags, &w->heads, &w->cub_tmp, &w->frame_tab };
+    Buf* bufs[] = { &w->setup, &w->keys_a, &w->keys_b, &w->vals_a, &w->vals_b, &w->flags, &w->heads, &w->cub_tmp, &w->frame_tab, &w->long_list };
     for (Buf* b : bufs) if (b->p) (void)hipFree(b->p);
     if (w->h_setup) (void)hipHostFree(w->h_setup);
     delete w;
@@ -265,6 +346,7 @@ hipError_t vox_downsample(VoxWorkspace* w, hipStream_t stream, const unsigned ch
     VOX_TRY(w->keys_a.ensure(4 * n)); VOX_TRY(w->keys_b.ensure(4 * n));
     VOX_TRY(w->vals_a.ensure(4 * n)); VOX_TRY(w->vals_b.ensure(4 * n));
     VOX_TRY(w->flags.ensure(n));      VOX_TRY(w->heads.ensure(4 * n));
+    VOX_TRY(w->long_list.ensure(4 * (n / kLongRun + 1)));          // (a long run holds more than kLongRun points)
     VoxSetup* s = w->setup.as<VoxSetup>();
     uint32_t* keys_a = w->keys_a.as<uint32_t>(); uint32_t* keys_b = w->keys_b.as<uint32_t>();
     int32_t* vals_a = w->vals_a.as<int32_t>();   int32_t* vals_b = w->vals_b.as<int32_t>();
@@ -290,7 +372,12 @@ hipError_t vox_downsample(VoxWorkspace* w, hipStream_t stream, const unsigned ch
     VOX_TRY(hipcub::DeviceSelect::Flagged(w->cub_tmp.p, tb, counting, flags, heads, &s->n_out, ni, stream));
     // launched for the worst case (one voxel per point); lanes past n_out exit on the device-side count
     hipLaunchKernelGGL(k_vox_centroid, dim3(nb), dim3(256), 0, stream, d_in, stride, (const int32_t*)vals_b,
-                       (const int32_t*)heads, (const VoxSetup*)s, d_out, out_stride, (int)(cap < n ? cap : n));
+                       (const int32_t*)heads, s, w->long_list.as<int32_t>(), d_out, out_stride, (int)(cap < n ? cap : n));
+    {   // the long runs, a wave each (the grid walks the list the kernel above left)
+        const int nl = ni / kLongRun + 1;
+        hipLaunchKernelGGL(k_vox_centroid_long, dim3(nl < 4096 ? (nl + 3) / 4 : 1024), dim3(256), 0, stream, d_in, stride, (const int32_t*)vals_b,
+                           (const int32_t*)heads, (const VoxSetup*)s, (const int32_t*)w->long_list.as<int32_t>(), d_out, out_stride);
+    }
     VOX_TRY(hipGetLastError());
     VOX_TRY(hipMemcpyAsync(w->h_setup, s, sizeof(VoxSetup), hipMemcpyDeviceToHost, stream));
     VOX_TRY(hipStreamSynchronize(stream));

@@ -36,6 +36,28 @@ def test_voxel_grid_bit_exact(gpu, n, leaf):
     _same_records(out, ref)
 
 
+def test_voxel_grid_long_runs_bit_exact(gpu):
+    """Voxels that hold hundreds / thousands of points (overlapping key frames, the sensor's near field) are summed by a whole
+    wave - 64 records gathered at a time, four lanes adding one component each in the run's order - and must give the bits of
+    the oracle's sequential fp32 sums: runs of 97 .. 20 000 points next to ordinary ones, 12- and 32-byte records."""
+    rng = np.random.default_rng(3)
+    parts = [raw_cloud(4000)]
+    for k, m in enumerate((97, 128, 129, 640, 5000, 20000)):
+        blob = np.zeros((m, 8), np.float32)
+        blob[:, :3] = (np.array([3.0 + 2.0 * k, -4.0, 0.3]) + rng.uniform(0.01, 0.37, (m, 3))).astype(np.float32)
+        blob[:, 3] = 1.0
+        blob[:, 4] = rng.uniform(0, 255, m).astype(np.float32)
+        parts.append(blob)
+    rec = np.concatenate(parts, 0)
+    rec = rec[rng.permutation(rec.shape[0])]
+    for leaf in (0.4, 0.5):
+        ref, _ = O.voxel_grid(rec, leaf)
+        _same_records(gpu.voxelGrid(rec, leaf), ref)
+    xyz = np.ascontiguousarray(rec[:, :3])
+    ref3, _ = O.voxel_grid(xyz, 0.4)
+    assert np.array_equal(gpu.voxelGrid(xyz, 0.4)[:, :3].view(np.uint32), ref3[:, :3].view(np.uint32))
+
+
 def test_voxel_grid_strides_and_edge_cases(gpu):
     rec = raw_cloud(5000)
     ref, _ = O.voxel_grid(rec, 0.4)
