@@ -216,11 +216,8 @@ def main(argv=None):
 
 def run(args):
 
-    # HIP spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), round-robin in creation order; two
-    # streams that land on one queue run strictly one after the other.  This process creates several engines (each with its
-    # stream, the pipelined ones with two slot streams more): with 4 queues the slot streams of the pipelined figure may share
-    # a queue and lose their overlap (measured: 0.628 -> 0.667 ms per scan, tools/experiments/exp15.py); 8 queues keep them apart.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    # (no GPU_MAX_HW_QUEUES setting any more: the slot streams of the pipelined figure have different priorities and so never
+    # share a hardware queue - liorf_amd/csrc/s2m_abi.hip, ensure_kids; tools/experiments/hw_queue_overlap.py)
     import torch
     import torch.distributed as dist
     from liorf_amd import batch, s2m, synth

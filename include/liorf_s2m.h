@@ -198,50 +198,12 @@ int  s2m_surf_optimization(s2m_handle h, const float pose[6],
 /* matAtA / matAtB / laserCloudSelNum of one iteration at `pose` (:1182-1239). */
 int  s2m_normal_eq(s2m_handle h, const float pose[6], float AtA[36], float AtB[6],
                    int32_t* n_sel);
-/* Observation hook: sinf / cosf (and atanf when `a` is not NULL) of n host floats as the device computes them -
- * sin/cos when it rebuilds the transform between LM iterations, atan in the ScanContext sector angle. They follow
- * the arithmetic of glibc's sinf / cosf / atanf, so that the device gives what the reference's host libm gives. */
-int  s2m_debug_device_trig(s2m_handle h, const float* x, size_t n, float* s, float* c, float* a);
 /* Raw device time (ms) of the last s2m_optimize* call, measured with HIP events
  * on the handle's stream; and of the last s2m_set_map / s2m_set_scan index build. */
 int  s2m_last_timing(s2m_handle h, float* optimize_ms, float* set_map_ms, float* set_scan_ms);
-/* Diagnostics: workgroups the certify kernels of the last collected loop handed to the search kernel (slot < 0: the handle's own
- * loop; slot >= 0: that scan slot of the last batch). */
-int  s2m_debug_deferred(s2m_handle h, int slot);
-/* Benchmark helper: runs `reps` complete LM loops (max_iter iterations, early exit as
- * configured, each loop starting like a fresh scan) on the resident scan + map with plain
- * launches and a HIP-event pair on the handle's stream around every launch of the
- * per-iteration registration kernel (k_register: kNN + plane + Jacobian + block reduction);
- * returns the mean duration of those launches in ms. */
-int  s2m_time_iteration_kernel(s2m_handle h, const float pose[6], int reps, float* ms_per_launch);
-/* Same measurement, reported per LM iteration: ms_per_iter[it] = mean duration of launch `it` of the
- * loop over `reps` loops (cap >= max_iter entries). The first launches of a scan search without a prior
- * and cost more than the steady state. */
-int  s2m_time_iterations(s2m_handle h, const float pose[6], int reps, float* ms_per_iter, int cap);
-
-/* Benchmark helper: mean duration (microseconds) of a k_register launch over `reps` whole LM loops as the fused loop issues them,
- * measured with HIP events on the handle's stream around launch 0, launch 1, the run of back-to-back launches 2 .. max_iter-2 and
- * the last launch - four event pairs per loop instead of max_iter, so the event packets do not break up the back-to-back dispatch
- * (the gaps between consecutive launches are part of the figure). */
-int  s2m_time_loop_launches(s2m_handle h, const float pose[6], int reps, float* us_per_launch);
-
-/* Diagnostics: a full loop from `pose` (early_exit must be off), then `reps` back-to-back replays of its last registration
- * launch in the state the loop ended in; solve_prev != 0 closes the iteration before it in the launch's prologue each time
- * (the steady launch of the fused loop), 0 only rebuilds the transform.  Mean microseconds per replayed launch, gaps included. */
-int  s2m_debug_time_steady(s2m_handle h, const float pose[6], int reps, int solve_prev, float* us_per_launch);
-
-/* Diagnostics: `launches` > 0: that many k_register passes at `pose`, the last one recorded (1 = the pass
- * that inherits its prior from whatever ran before, 3 = steady state at this pose). `launches` < 0: a real LM
- * loop from `pose` exactly as s2m_optimize issues it, of which launch number N = -launches - 1 is recorded
- * (N = 0: the first launch of a scan, searching without a prior), including the fused close of the
- * iteration before it. Per wave (up to 64 locality-sorted scan points) S2M_PROF_WORDS words:
- * [0..3] wall clock (100 MHz) at start / after the search / after plane+Jacobian / at end; [4] search path
- * (1 LDS tile, 2 gather), [5] box rows, [6] points visited, [7] raw points; [8..12] ticks spent in
- * prior+box / row marking, points in the wave, staging, search; [13..15] path details; [16..22] wall clock
- * of the fused LM close: entry, partial sums reduced, normal equations, QR solved, update done, barrier
- * passed, transform built (0 when the launch closes nothing). Returns the number of waves written. */
-#define S2M_PROF_WORDS 32
-int  s2m_debug_wave_profile(s2m_handle h, const float pose[6], int launches, uint64_t* out, size_t cap_waves);
+/* Diagnostic and benchmark entry points (per-launch timing, per-wave profiles, the device's trig arithmetic, experiment
+ * switches read from the environment) are declared in liorf_s2m_debug.h: they are exported by the same library but are not part
+ * of the boundary a node binds. */
 
 /* ---- The voxel-grid stages either side of the path ----------
  * pcl::VoxelGrid<pcl::PointXYZI>::applyFilter with the reference's settings (all fields averaged,

@@ -1096,7 +1096,15 @@ int ensure_kids(s2m_context* h, int n)
         h->kids.push_back(k);
         hipStream_t st = nullptr;
         hipEvent_t ev = nullptr, ev2 = nullptr;
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
+        // The streams of neighbouring slots get different priorities.  HIP deals a process's streams of one priority onto a small
+        // pool of hardware queues in creation order (GPU_MAX_HW_QUEUES, default 4), and two streams that land on one queue run
+        // strictly one after the other: with other streams alive in the process (a ROS node has them) the two slots of a stream
+        // of scans could end up sharing a queue and lose the overlap of one's preparation with the other's loop.  Streams of
+        // different priority never share a hardware queue, whatever else the process has created.
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        const int prio = (h->kids.size() & 1) ? prio_greatest : prio_least;
+        if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio) != hipSuccess || hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ev2, hipEventDisableTiming) != hipSuccess)
             return fail(h, S2M_ERR_HIP, "batch: stream / event creation failed");
         h->branch_streams.push_back(st);

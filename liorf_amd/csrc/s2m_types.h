@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 #include "../../include/liorf_s2m.h"
+#include "../../include/liorf_s2m_debug.h"
 
 namespace s2m {
 
