@@ -262,7 +262,9 @@ static_assert(kTilePts <= (1 << kSlotBits), "tile slots must fit the key's low b
 // LEAN: the 128-register builds (two workgroups per CU: the scan slots of a batch, the 16-wave shape of large scans).  There a
 // pass stores its lanes' fronts straight from the tile and the plane fit fetches the five points again from the map
 // (L2-warm), instead of carrying 24 registers of coordinates through the passes that may follow.
-template <bool HOOK, bool LEAN>
+// WALK: the lanes of a scattered sparse wave may walk their own cells (not in the scan slots of a batch, whose kernel is
+// measurably slower for every line of search code it carries).
+template <bool HOOK, bool LEAN, bool WALK>
 __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr<const v4f> map,
                                                 gptr<const int32_t> cell_start, const float (&T)[12], float gatef, int ablate,
                                                 int2 chunk, int lane, v4f* lpts, int2* lrows,
@@ -621,7 +623,7 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
             // too dense or too scattered for one tile: again with fewer lanes (half, or the next power of two below), or - a
             // handful of lanes - served one by one
             if (!few && nA > kServeLanes && !(ablate & 64)) {
-                if (scattered && group == 64) {
+                if (WALK && scattered && group == 64) {
                     // A box too wide for its lanes, at the first attempt.  Fewer lanes may share a pass (consecutive lanes are
                     // neighbours) - but the lanes of a sparse far-field ring segment are metres apart one by one, and end up served
                     // one after the other, 1.5 us each.  If every lane has few candidates in its own cells - fewer than serving
@@ -766,7 +768,7 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
         }
         // ---- lanes that walk their own 3x3x3 cells, all at once: the lanes of passes too scattered to stage, and lanes with more
         // candidates than the served path holds
-        const bool walker = searching && ((walk >> lane) & 1ull) != 0ull;
+        const bool walker = searching && ((walk >> lane) & 1ull) != 0ull;     // (128-register builds: only lanes the served path could not hold)
         if (__ballot(walker)) {
             if (HOOK) prof.mode = 3;
             int2* lruns = reinterpret_cast<int2*>(lpts);
@@ -1522,7 +1524,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                         cert = G((const v4f*)cp->cert)[i];
                     }
                 }
-                associate_chunk<HOOK, (MINW > 2)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
+                associate_chunk<HOOK, (MINW > 2), !(NW == 8 && MINW == 4)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                                       px, py, pz, cert, prof);
             }
             if (HOOK) clk1 = wall_clock64();
@@ -1628,7 +1630,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
             if (MODE == kCertify) {
                 defer = __ballot(need) != 0ull && !quick;                            // this workgroup's row is the search kernel's business
             } else if (HOOK || __builtin_expect(__ballot(need) != 0ull && !quick, 0)) {     // (unlikely: the search is laid out away from the certified path)
-                associate_chunk<HOOK, (MINW > 2)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
+                associate_chunk<HOOK, (MINW > 2), !(NW == 8 && MINW == 4)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                                       px, py, pz, cert, prof);
                 // The point is read again (L2-warm) rather than kept in registers through the association: what the
                 // certified path holds in registers must not be live across the search, or the allocator spills it on
@@ -1680,7 +1682,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                 cert = G((const v4f*)cp->cert)[i];
             }
         }
-        associate_chunk<HOOK, (MINW > 2)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
+        associate_chunk<HOOK, (MINW > 2), !(NW == 8 && MINW == 4)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
                               px, py, pz, cert, prof);
     }
     }
