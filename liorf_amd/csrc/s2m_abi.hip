@@ -91,6 +91,8 @@ struct s2m_context {
     bool slot_mode = false;            // (a slot running a loop of its own on its own stream: s2m_slot_optimize_*)
     bool state_borrowed = false;       // (a slot: `state` and `h_state` point into the parent's blocks)
     std::map<std::vector<int>, hipGraphExec_t> batch_graphs;
+    std::vector<int> batch_live;          // the slots of the batch in flight that run a loop
+    bool batch_seg_pending = false;       // the batch in flight was issued as its first range of launches only (early exit on)
     unsigned long long map_epoch = 0;     // bumped by every s2m_set_map: children re-adopt the index when it changed
     unsigned long long adopted_epoch = 0;
 
@@ -604,7 +606,7 @@ void enqueue_loop(s2m_context* h, const LoopShape& sh_in, hipEvent_t* events, bo
     LoopShape sh = sh_in;
     // S2M_SPLIT=2: from launch `split_from` on (the first launches search most points: there the certify kernel is only one
     // more launch in front of the search) the iterations of a loop closed by k_finalize run certify (lean) + search
-    const bool split_late = sh.split_auto && !fuse && sh.wpb == kBlock / 64 && h->lean_certify && !h->prm.early_exit;   // (a loop that breaks early never gets there)
+    const bool split_late = sh.split_auto && !fuse && sh.wpb == kBlock / 64 && h->lean_certify;   // (with early exit on these launches are the second range: issued only for scans that need them)
     if (h->density_raw > 0 && L0 == 0) launch_density(h, sh);
     for (int L = L0; L < L1; L++) {
         const int slot = !coarse ? 2 * L : (L == 0 ? 0 : (L == 1 ? 2 : (L == n - 1 ? 6 : 4)));
@@ -1120,9 +1122,11 @@ int ensure_kids(s2m_context* h, int n)
 // One graph for the whole batch.  Lockstep (default): the slots' loops advance together, every launch of the loop has one
 // grid row per slot (slots of different workgroup shape form groups, one loop per group on a branch of its own).  Otherwise
 // (S2M_LOCKSTEP=0, A/B measurements): a fork, one branch per scan with that scan's loop, a join.
-int get_batch_graph(s2m_context* h, const std::vector<int>& live, hipGraphExec_t* out)
+// part 0: the whole loop; 1: launches 0 .. seg-1; 2: launches seg .. max_iter-1 (as get_graph)
+int get_batch_graph(s2m_context* h, const std::vector<int>& live, int part, hipGraphExec_t* out)
 {
     std::vector<int> key;
+    key.push_back(part); key.push_back(part ? h->seg_iters : 0);
     for (int b : live) { key.push_back(b); key.push_back(h->kids[(size_t)b]->hctx.table_cap); key.push_back(h->kids[(size_t)b]->hctx.wpb); }
     auto it = h->batch_graphs.find(key);
     if (it != h->batch_graphs.end()) { *out = it->second; return S2M_OK; }
@@ -1157,7 +1161,7 @@ int get_batch_graph(s2m_context* h, const std::vector<int>& live, hipGraphExec_t
         hipStream_t br = h->branch_streams[j];
         ok = ok && hipStreamWaitEvent(br, h->ev_fork, 0) == hipSuccess;
         h->stream = br;                                       // (enqueue_loop launches on the handle's stream; settings are the parent's)
-        enqueue_loop(h, loops[j], nullptr);
+        enqueue_loop(h, loops[j], nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
         h->stream = keep;
         ok = ok && hipEventRecord(h->branch_events[j], br) == hipSuccess;
         ok = ok && hipStreamWaitEvent(h->stream, h->branch_events[j], 0) == hipSuccess;
@@ -1319,10 +1323,15 @@ int s2m_optimize_batch_launch(s2m_handle h, int n_scans, const float* poses)
         flush_init();
         S2M_HIP(h, hipGetLastError());
     }
+    // With early exit on the loops are issued as launches 0 .. seg-1 and, only if some slot has not converged by then, the rest
+    // (s2m_optimize_batch_collect looks at the slots' `done` flags, which come back with the states anyway): the launches behind
+    // the convergence of every slot - idle, but a kernel boundary and a k_finalize each - were a fifth of an early-exit batch.
+    h->batch_seg_pending = h->prm.early_exit && h->seg_iters > 1 && h->seg_iters < h->prm.max_iter;
+    h->batch_live = live;
     S2M_HIP(h, hipEventRecord(h->ev_a, h->stream));
     if (!live.empty()) {
         hipGraphExec_t exec = nullptr;
-        if ((rc = get_batch_graph(h, live, &exec))) return rc;
+        if ((rc = get_batch_graph(h, live, h->batch_seg_pending ? 1 : 0, &exec))) return rc;
         S2M_HIP(h, hipGraphLaunch(exec, h->stream));
     }
     S2M_HIP(h, hipEventRecord(h->ev_b, h->stream));
@@ -1342,6 +1351,27 @@ int s2m_optimize_batch_collect(s2m_handle h, int n_scans, float* poses, const s2
     S2M_HIP(h, hipSetDevice(h->device));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
     S2M_HIP(h, hipEventElapsedTime(&h->t_optimize_ms, h->ev_a, h->ev_b));
+    if (h->batch_seg_pending && !h->batch_live.empty()) {
+        h->batch_seg_pending = false;
+        bool all_done = true;
+        for (int b : h->batch_live) all_done = all_done && h->kids[(size_t)b]->h_state[1].done != 0;
+        if (!all_done) {
+            // some slot needs more than the first range: the rest of the loop for all of them (a converged slot's launches return at once)
+            hipGraphExec_t exec = nullptr;
+            int rc2 = get_batch_graph(h, h->batch_live, 2, &exec);
+            if (rc2) return rc2;
+            S2M_HIP(h, hipEventRecord(h->ev_a2, h->stream));
+            S2M_HIP(h, hipGraphLaunch(exec, h->stream));
+            S2M_HIP(h, hipEventRecord(h->ev_b2, h->stream));
+            constexpr size_t kStride = sizeof(DevState) + sizeof(s2m_iter_trace) * kMaxIter;
+            const size_t upto = (size_t)h->batch_live.back() + 1;
+            S2M_HIP(h, hipMemcpyAsync(h->h_kid_states + sizeof(DevState), h->kid_states.p, kStride * upto, hipMemcpyDeviceToHost, h->stream));
+            S2M_HIP(h, hipStreamSynchronize(h->stream));
+            float t2 = 0.0f;
+            S2M_HIP(h, hipEventElapsedTime(&t2, h->ev_a2, h->ev_b2));
+            h->t_optimize_ms += t2;
+        }
+    }
     for (int b = 0; b < n_scans; b++) {
         s2m_context* k = h->kids[(size_t)b];
         const int rc = s2m_optimize_collect(k, poses + 6 * (size_t)b, imu ? imu + b : nullptr, out ? out + b : nullptr);

@@ -24,24 +24,30 @@
 //           The margin (2 um) is twenty times the fp32 rounding of the distance arithmetic (1e-7 relative
 //           on distances below 1 m; the triangle inequality itself is exact for the rounded positions the
 //           reference measures from); tuples with an exact tie (gap 0) never get a certificate.
-//   tier B  re-measure.  A point that moved farther than its slack fetches its 5 stored neighbours
-//           (by position in the cell-sorted map) and measures them again.  If the new 5th distance is
-//           still below r6 - e, the SET is unchanged; order, gate and slack are refreshed, the plane is
-//           refitted only if the order changed.
-//   tier C  search.  Only the lanes that fail A and B search: the tile path (compact waves: box rows
-//           staged through a filter into the wave's LDS tile, count verification against the re-measured
-//           tuple's 5th distance, candidate lists, wave-wide insertion) or, when a handful of lanes is
-//           left or the wave is scattered, the gather path (each lane walks the <= 9 x-runs of its own
-//           3x3x3 cells in the L2-resident map).  The search looks kCertDelta beyond the 5th distance so
-//           that the count sweep, which sees every point there anyway, also yields r6 for the next
-//           certificate.  Search keys are (fp32 d2 bits << 32 | map position): one 64-bit compare orders
-//           them, and the position fetches coordinates and the original map index afterwards.  The
-//           reference order (d2, original index) differs from (d2, position) only between points at exactly
-//           equal distance: ties inside the tuple are re-ordered after the fetch, a tie across the 5th/6th
-//           boundary is detected during insertion and settled by an exact walk over the lane's cells.
+//   tier B  re-measure.  Besides its tuple a point keeps its FRONT: the (up to) six nearest map points it knew when it last
+//           searched - EVERY map point within r_out of q_ref - with their coordinates (96 bytes).  A point that moved farther
+//           than its slack measures those six again, without touching the map: everything else is at least r_out - e away, so
+//           if the new 5th distance is below that the tuple is proved; order, gate and slack are refreshed, the plane is
+//           refitted only if the order changed.  A point the front does not settle takes the 5th distance along as the bound
+//           of its search.
+//   tier C  search.  Only the lanes that fail A and B search.  The box rows the lanes of a pass need are streamed through a
+//           filter into the wave's LDS tile (sixteen rows in flight per round trip); every lane then keeps the SEVEN nearest
+//           tile points in a sorted list of 32-bit keys - the bits of the squared distance with the low 9 replaced by the tile
+//           slot - by one v_med3_u32 per list element and tile point (near7_insert): 17 instructions per lane and tile point,
+//           whatever the lane finds (round 3's count / list / select sweeps: ~80).  The six nearest by key are then measured
+//           exactly from the tile (LDS) and put in exact order; the 7th key's distance part bounds everything else from below,
+//           and the answer stands if the exact 5th distance is below that bound (a near-tie the keys cannot resolve - 18 um at
+//           0.6 m - is served exactly instead).  Idle lanes share the sweep of passes with few searching lanes; a box that
+//           overflows the tile is swept in chunks with a running list (256-register builds) or split into passes of fewer
+//           lanes (128-register builds); a handful of leftover lanes are served one by one (the wave reads a lane's <= 9
+//           x-runs cooperatively); the lanes of a wave too scattered to share anything - a sparse far-field ring segment -
+//           walk their own cells, every lane for itself and all at once.  Exact keys are (fp32 d2 bits << 32 | map position);
+//           the reference order (d2, original index) differs only between points at exactly equal distance: ties inside the
+//           six are re-ordered after a fetch from the map, a tie across the 5th/6th boundary is settled by an exact walk.
 //
 // In the steady state of the loop (pose steps of 1e-4 m and less) nearly every wave is all tier A: it
 // reads 44 bytes per point (position, certificate, plane) and no map data at all.
+// Round 4 rebuilt tiers B and C (fronts with coordinates, the key sweep): launch 0 of a kitti64 scan 71 -> 40 us.
 //
 // Two passes per wave, so that the 28 fp64 sums of the normal equations never coexist with the search's
 // registers:  pass 1 (associate) brings every point's tuple / plane / certificate up to date for this
