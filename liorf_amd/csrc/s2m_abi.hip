@@ -632,6 +632,9 @@ int get_graph(s2m_context* h, int nblocks, int part, hipGraphExec_t* out)
     hipGraphExec_t exec = nullptr;
     S2M_HIP(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     enqueue_loop(h, sh, nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
+    // loop state + trace come back as the last node of the graph (into the pinned mirror: its address never changes): a copy
+    // issued behind the graph starts ~10 us after the graph's last kernel
+    (void)hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream);
     hipError_t e = hipStreamEndCapture(h->stream, &graph);
     if (e != hipSuccess || !graph) return fail(h, S2M_ERR_HIP, "hipStreamEndCapture", e);
     e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -662,6 +665,7 @@ int launch_loop(s2m_context* h, int part = 0)
     enqueue_loop(h, shape_of(h), nullptr, false, part == 2 ? h->seg_iters : 0, part == 1 ? h->seg_iters : -1);
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipEventRecord(e1, h->stream));
+    S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
     h->hctx.density_pending = 0;
     return S2M_OK;
 }
@@ -960,8 +964,7 @@ int s2m_optimize_launch(s2m_handle h, const float pose[6])
     int rc;
     if ((rc = push_state(h, pose))) return rc;             // (with the DevCtx block when that changed)
     h->seg_pending = h->prm.early_exit && h->seg_iters > 1 && h->seg_iters < h->prm.max_iter;
-    if ((rc = launch_loop(h, h->seg_pending ? 1 : 0))) return rc;
-    S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
+    if ((rc = launch_loop(h, h->seg_pending ? 1 : 0))) return rc;        // (state + trace come back with it)
     return S2M_OK;
 }
 
@@ -985,7 +988,6 @@ int s2m_optimize_collect(s2m_handle h, float pose[6], const s2m_imu_init* imu, s
             // the first range did not converge: the rest of the loop
             int rc2 = launch_loop(h, 2);
             if (rc2) return rc2;
-            S2M_HIP(h, hipMemcpyAsync(&h->h_state[1], h->state.p, sizeof(DevState) + sizeof(s2m_iter_trace) * h->prm.max_iter, hipMemcpyDeviceToHost, h->stream));
             S2M_HIP(h, hipStreamSynchronize(h->stream));
             float t2 = 0.0f;
             S2M_HIP(h, hipEventElapsedTime(&t2, h->ev_a2, h->ev_b2));

@@ -96,6 +96,16 @@ __device__ __forceinline__ uint64_t top6k_insert(Top6k& t, uint64_t key)
     return key;
 }
 
+// six keys in any order -> ascending: the 12-comparator network for six inputs (a third of six insertions)
+__device__ __forceinline__ void sort6k(Top6k& t)
+{
+    cas_u64(t.key[0], t.key[5]); cas_u64(t.key[1], t.key[3]); cas_u64(t.key[2], t.key[4]);
+    cas_u64(t.key[1], t.key[2]); cas_u64(t.key[3], t.key[4]);
+    cas_u64(t.key[0], t.key[3]); cas_u64(t.key[2], t.key[5]);
+    cas_u64(t.key[0], t.key[1]); cas_u64(t.key[2], t.key[3]); cas_u64(t.key[4], t.key[5]);
+    cas_u64(t.key[1], t.key[2]); cas_u64(t.key[3], t.key[4]);
+}
+
 // exact top-5 of the fallback sweep (a neighbourhood that would not fit): same keys
 struct Top5k { uint64_t key[5]; };
 __device__ __forceinline__ void top5k_insert(Top5k& t, uint64_t key)
@@ -365,8 +375,9 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
                 const bool on = ev && k < nb_n;
                 float d2;
                 const uint64_t key = make_key(fr[k], sx, sy, sz, d2);
-                top6k_insert(top, on ? key : kKeyInf);
+                top.key[k] = on ? key : kKeyInf;
             }
+            sort6k(top);
             const float r = r_out - eps;
             const float d2_5 = __uint_as_float(key_hi(top.key[4]));
             const bool have5 = key_hi(top.key[4]) < 0x7f800000u;
@@ -517,15 +528,14 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
         // >= a[6]: its true squared distance is at least a[6]'s distance part (returned).
         auto exact_six = [&](const uint32_t (&a)[7], Top6k& t) -> float {
 #pragma unroll
-            for (int k = 0; k < 6; k++) t.key[k] = kKeyInf;
-#pragma unroll
             for (int k = 0; k < 6; k++) {
                 const bool have = act && a[k] != kNoKey;
                 const int jk = have ? (int)(a[k] & kSlotMask) : 0;
                 float d2;
                 make_key(lpts[jk], sx, sy, sz, d2);
-                top6k_insert(t, (have && d2 <= rim2p) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)jk) : kKeyInf);
+                t.key[k] = (have && d2 <= rim2p) ? (((uint64_t)__float_as_uint(d2) << 32) | (uint32_t)jk) : kKeyInf;
             }
+            sort6k(t);
             return (a[6] != kNoKey) ? __uint_as_float(a[6] & ~kSlotMask) : INFINITY;
         };
         // A box that holds more points than the tile: the tile is swept whenever it is full, its six go into the lane's running
@@ -1301,8 +1311,9 @@ __global__ __launch_bounds__(NW / EPW * 64, MINW) void k_certify_lean(const Slot
                     for (int k = 0; k < 6; k++) {
                         float d2;
                         const uint64_t key = make_key(fr[k], sx, sy, sz, d2);            // L2_Simple order; low word: the member's map position
-                        top6k_insert(t, (okl && k < nfr) ? key : kKeyInf);
+                        t.key[k] = (okl && k < nfr) ? key : kKeyInf;
                     }
+                    sort6k(t);
                 }
                 const float r = __int_as_float(aux.w) - eps;                            // everything outside the six is at least this far away
                 const float d2_5 = __uint_as_float(key_hi(t.key[4]));
@@ -1569,8 +1580,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                     for (int k = 0; k < 6; k++) {
                         float d2;
                         const uint64_t key = make_key(frag.fr[k], sx, sy, sz, d2);       // L2_Simple order; low word: the member's map position
-                        top6k_insert(t, (okl && k < nfr) ? key : kKeyInf);
+                        t.key[k] = (okl && k < nfr) ? key : kKeyInf;
                     }
+                    sort6k(t);
                     const float r = __int_as_float(frag.aux.w) - eps;                   // everything outside the six is at least this far away
                     const float d2_5 = __uint_as_float(key_hi(t.key[4]));
                     okl = okl && key_hi(t.key[4]) < 0x7f800000u && ((double)d2_5 < cp->gate_sq) && (sqrtf(d2_5) + kCertMargin < r);
