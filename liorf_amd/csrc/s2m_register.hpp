@@ -71,7 +71,7 @@ constexpr float kSlabRound = 1e-6f;    // rounding of the cell binning per metre
 constexpr float kAbsRound = 2.4e-7f;   // two ulps of an absolute coordinate, per metre of it
 constexpr int   kTilePad = 32;         // far-away entries behind a tile's last point (four steps of up to eight parts)
 constexpr int   kShareMin = 24;        // tile points from which idle lanes share the sweep of a pass with few searching lanes
-constexpr int   kWalkPerLane = 6;      // a scattered wave's lanes walk their own cells if none has more candidates than this times the lanes to do
+constexpr int   kWalkMax = 384;        // a scattered wave's lanes walk their own cells (in teams: idle lanes join in) if none has more candidates than this
 constexpr int   kServeLanes = 4;       // up to this many leftover lanes of a pass that cannot be staged are served one by one; more are split further
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));
@@ -210,18 +210,22 @@ __device__ __forceinline__ int walk_runs(gptr<const int32_t> cell_start, const G
     return P;
 }
 
-__device__ __forceinline__ void walk_top7(gptr<const v4f> map, float sx, float sy, float sz, int lane, const int2* lruns, uint64_t (&f)[7])
+// `own`: the lane whose runs are walked (its column of lruns); `part` / `team`: this lane takes candidates part, part + team, ...
+// of every run (a team of lanes shares one searching point: the parts' lists are merged by the caller).
+__device__ __forceinline__ void walk_top7(gptr<const v4f> map, float sx, float sy, float sz, int own, int part, int team, bool on,
+                                          const int2* lruns, uint64_t (&f)[7])
 {
 #pragma unroll
     for (int k = 0; k < 7; k++) f[k] = kKeyInf | 0xffffffffull;
 #pragma unroll 1
     for (int k = 0; k < 9; k++) {
-        const int2 r = lruns[k * 64 + lane];
+        const int2 r = lruns[k * 64 + own];
+        const int end = on ? r.y : r.x;
 #pragma unroll 1
-        for (int j = r.x; j < r.y; j += 2) {
-            const bool two = j + 1 < r.y;
-            v4f m0 = map[j], m1 = map[two ? j + 1 : j];
-            m0.w = __int_as_float(j); m1.w = __int_as_float(j + 1);
+        for (int j = r.x + part; j < end; j += 2 * team) {
+            const bool two = j + team < end;
+            v4f m0 = map[j], m1 = map[two ? j + team : j];
+            m0.w = __int_as_float(j); m1.w = __int_as_float(j + team);
             float d0, d1;
             const uint64_t k0 = make_key(m0, sx, sy, sz, d0);
             const uint64_t k1 = two ? make_key(m1, sx, sy, sz, d1) : (kKeyInf | 0xffffffffull);
@@ -647,7 +651,7 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
                     int2* lruns = reinterpret_cast<int2*>(lpts);
                     const int P = walk_runs(cell_start, g, cx, cy, cz, be2, gx2m, gx2p, gy2m, gy2p, gz2m, gz2p, lane, lruns);
                     wave_lds_sync();                      // (the tile area is the next pass's again)
-                    if (wave_max_i32(act ? P : 0) < kWalkPerLane * nA) { walk |= amask; todo &= ~amask; continue; }
+                    if (wave_max_i32(act ? P : 0) < kWalkMax) { walk |= amask; todo &= ~amask; continue; }
                 }
                 group = (nA > 32) ? 32 : ((nA > 16) ? 16 : ((nA > 8) ? 8 : 4));
                 continue;
@@ -784,14 +788,46 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
         }
         // ---- lanes that walk their own 3x3x3 cells, all at once: the lanes of passes too scattered to stage, and lanes with more
         // candidates than the served path holds
-        const bool walker = searching && ((walk >> lane) & 1ull) != 0ull;     // (128-register builds: only lanes the served path could not hold)
-        if (__ballot(walker)) {
+        const bool walker = searching && ((walk >> lane) & 1ull) != 0ull;     // (batch-slot builds: only lanes the served path could not hold)
+        if (walk) {
             if (HOOK) prof.mode = 3;
             int2* lruns = reinterpret_cast<int2*>(lpts);
             (void)walk_runs(cell_start, g, cx, cy, cz, be2, gx2m, gx2p, gy2m, gy2p, gz2m, gz2p, lane, lruns);
+            // Idle lanes join in: with nW <= 32 walking lanes, teams of 2, 4 or 8 lanes share one walking point - lane l works for
+            // the walking lane of rank l % nslot and takes every team-th candidate of its runs; the parts' lists are merged by a
+            // butterfly, and the walking lane of rank r picks its result up from lane r.  (The waves that walk are the short ones
+            // of split chunks in the sparse far field: 8 or 16 points, the rest of the wave idle - and a walk is latency-bound.)
+            const int nW = __popcll(walk);
+            const int team = (nW > 32) ? 1 : ((nW > 16) ? 2 : ((nW > 8) ? 4 : 8));
+            const int nslot = 64 / team, part = lane / nslot, s_ = lane & (nslot - 1);
+            int* lown = reinterpret_cast<int*>(lrows);
+            const int rank = __popcll(walk & ((1ull << lane) - 1ull));
+            if (walker) lown[rank] = lane;
+            wave_lds_sync();
+            const bool on = s_ < nW;
+            const int own = on ? lown[s_] : lane;
+            const int col = walker ? rank : lane;
+            const float qx_ = __shfl(sx, own, 64), qy_ = __shfl(sy, own, 64), qz_ = __shfl(sz, own, 64);
+            uint64_t found[7];
+            walk_top7(map, qx_, qy_, qz_, own, part, team, on, lruns, found);
+            for (int m = nslot; m < 64; m <<= 1) {            // merge the parts' lists
+                uint64_t o[7];
+#pragma unroll
+                for (int k = 0; k < 7; k++)
+                    o[k] = ((uint64_t)(uint32_t)__shfl_xor((int)key_hi(found[k]), m, 64) << 32) | (uint32_t)__shfl_xor((int)key_lo(found[k]), m, 64);
+#pragma unroll
+                for (int k = 0; k < 7; k++) {
+                    if (o[k] < found[6]) {
+                        found[6] = o[k];
+#pragma unroll
+                        for (int q = 6; q > 0; --q) cas_u64(found[q - 1], found[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 7; k++)
+                found[k] = ((uint64_t)(uint32_t)__shfl((int)key_hi(found[k]), col, 64) << 32) | (uint32_t)__shfl((int)key_lo(found[k]), col, 64);
             if (walker) {
-                uint64_t found[7];
-                walk_top7(map, sx, sy, sz, lane, lruns, found);
                 int n6 = 0;
 #pragma unroll
                 for (int r = 0; r < 6; r++) {
@@ -803,6 +839,7 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
                 rn = sqrtf(fminf(seven ? __uint_as_float(key_hi(found[6])) : INFINITY, rim2)) * 0.999999f;
                 nb_n = n6; nbr_ok = true; settled = true; have_nb = false;
             }
+            wave_lds_sync();
         }
         if (HOOK) prof.ts[3] = wall_clock64();
     }
