@@ -287,7 +287,7 @@ static_assert(kTilePts <= (1 << kSlotBits), "tile slots must fit the key's low b
 template <bool HOOK, bool LEAN, bool WALK>
 __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr<const v4f> map,
                                                 gptr<const int32_t> cell_start, const float (&T)[12], float gatef, int ablate,
-                                                int2 chunk, int lane, v4f* lpts, int2* lrows,
+                                                int2 chunk, int lane, v4f* lpts, int2* lrows, float* lkeep,
                                                 float px, float py, float pz, v4f cert, WaveProf& prof)
 {
     const int nq = cp->n_q;
@@ -938,10 +938,12 @@ __device__ __forceinline__ void associate_chunk(CtxP cp, const GridDesc& g, gptr
             }
             const v4f pl = { planeValid ? pa : NAN, pb, pc, pd };                     // pa = NaN: contributes nothing
             planep[i] = pl;
+            if (lkeep) { lkeep[3 * 64 + lane] = pl.x; lkeep[4 * 64 + lane] = pl.y; lkeep[5 * 64 + lane] = pl.z; lkeep[6 * 64 + lane] = pl.w; }
             pst = planeValid ? 1 : 2;
         } else if (!gated) {
             const v4f pl = { NAN, 0.0f, 0.0f, 0.0f };
             planep[i] = pl;
+            if (lkeep) { lkeep[3 * 64 + lane] = pl.x; lkeep[4 * 64 + lane] = pl.y; lkeep[5 * 64 + lane] = pl.z; lkeep[6 * 64 + lane] = pl.w; }
             pst = 0;
         }
         // the certificate for the launches to come: d1..d5, then the nearest of anything else - the 6th of the six or
@@ -1445,6 +1447,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
     static_assert(sizeof(v4f) * kTilePts >= sizeof(int32_t) * 18 * 64, "run table must fit the tile area");
     __shared__ double  red[CNW][32];
     __shared__ int2    s_rows[kTileWaves][kHasSearch ? 64 : 1];            // per wave: the non-empty box rows of the current row group
+    constexpr bool kKeep = kHasSearch && NW == 8 && MINW == 2;             // (one 8-wave workgroup per CU: LDS to spare; two per CU, or the 16-wave shape, fill it with tiles)
+    __shared__ float   s_keep[kKeep ? NW : 1][kKeep ? 7 : 1][kKeep ? 64 : 1]; // per wave: point + plane of the entry in hand, parked across the association
     __shared__ float   s_lm_out[8];                  // pose + loop-ended flag published by lm_close_iteration
     __shared__ LmShared s_lm;                        // (kCertify: the close has no tile area to borrow)
 
@@ -1579,7 +1583,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
                     }
                 }
                 associate_chunk<HOOK, (MINW > 2), !(NW == 8 && MINW == 4)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
-                                      px, py, pz, cert, prof);
+                                      nullptr, px, py, pz, cert, prof);
             }
             if (HOOK) clk1 = wall_clock64();
 #pragma unroll
@@ -1685,13 +1689,23 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
             if (MODE == kCertify) {
                 defer = __ballot(need) != 0ull && !quick;                            // this workgroup's row is the search kernel's business
             } else if (HOOK || __builtin_expect(__ballot(need) != 0ull && !quick, 0)) {     // (unlikely: the search is laid out away from the certified path)
+                // Point and plane are not kept in registers through the association: what the certified path holds in registers
+                // must not be live across the search, or the allocator spills it on the common path (measured: +1.1 us on every
+                // steady launch).  In the builds with one 8-wave workgroup per CU they are parked in LDS (the association writes the planes it fits there
+                // too): reading them back from memory queues the loads behind the association's fourteen stores.
+                float* lkeep = kKeep ? &s_keep[kKeep ? wave : 0][0][0] : nullptr;
+                if (kKeep) {
+                    lkeep[0 * 64 + lane] = px; lkeep[1 * 64 + lane] = py; lkeep[2 * 64 + lane] = pz;
+                    lkeep[3 * 64 + lane] = plane0.x; lkeep[4 * 64 + lane] = plane0.y; lkeep[5 * 64 + lane] = plane0.z; lkeep[6 * 64 + lane] = plane0.w;
+                }
                 associate_chunk<HOOK, (MINW > 2), !(NW == 8 && MINW == 4)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
-                                      px, py, pz, cert, prof);
-                // The point is read again (L2-warm) rather than kept in registers through the association: what the
-                // certified path holds in registers must not be live across the search, or the allocator spills it on
-                // the common path (measured: +1.1 us on every steady launch).
+                                      lkeep, px, py, pz, cert, prof);
                 asm volatile("" ::: "memory");
-                if (valid0) {
+                if (kKeep) {
+                    wave_lds_sync();
+                    px = lkeep[0 * 64 + lane]; py = lkeep[1 * 64 + lane]; pz = lkeep[2 * 64 + lane];
+                    plane0 = v4f{ lkeep[3 * 64 + lane], lkeep[4 * 64 + lane], lkeep[5 * 64 + lane], lkeep[6 * 64 + lane] };
+                } else if (valid0) {
                     const int i = chunk.x + lane;
                     px = G(cp->qx)[i]; py = G(cp->qy)[i]; pz = G(cp->qz)[i];
                     plane0 = G((const v4f*)cp->plane_cache)[i];
@@ -1738,7 +1752,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_register(const SlotTable tbl,
             }
         }
         associate_chunk<HOOK, (MINW > 2), !(NW == 8 && MINW == 4)>(cp, g, map, cell_start, T, gatef, ablate, chunk, lane, s_pts[wave], s_rows[wave],
-                              px, py, pz, cert, prof);
+                              nullptr, px, py, pz, cert, prof);
     }
     }
     if (HOOK) clk1 = wall_clock64();
