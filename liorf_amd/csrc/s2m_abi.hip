@@ -1913,9 +1913,12 @@ int s2m_sc_detect_loop(s2m_handle h, int32_t* loop_id, float* yaw_diff_rad, s2m_
                        (const float*)h->sc_store_ring.as<float>(), (const double*)h->sc_store_sector.as<double>(),
                        (int)h->sc_n, (int)h->sc_n_search, h->sc_res.as<ScDetectOut>());
     S2M_HIP(h, hipGetLastError());
-    ScDetectOut o;
-    S2M_HIP(h, hipMemcpyAsync(&o, h->sc_res.p, sizeof(o), hipMemcpyDeviceToHost, h->stream));
+    // (into the pinned staging block: a copy to pageable memory goes through the runtime's own staging and costs ~50 us more)
+    static_assert(sizeof(ScDetectOut) <= sizeof(double) * 1220, "the result fits the pinned ScanContext staging block");
+    S2M_HIP(h, hipMemcpyAsync(h->h_sc, h->sc_res.p, sizeof(ScDetectOut), hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
+    ScDetectOut o;
+    memcpy(&o, h->h_sc, sizeof(o));
     *loop_id = o.loop_id; *yaw_diff_rad = o.yaw_diff_rad;
     if (detail) {
         detail->min_dist = o.min_dist; detail->nn_idx = o.nn_idx; detail->nn_align = o.nn_align;
