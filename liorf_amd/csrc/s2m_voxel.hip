@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void k_vox_centroid_long(const unsigned char* 
                                                            unsigned char* __restrict__ out, size_t out_stride)
 {
     constexpr int kChunk = 256;                      // records per round trip: four per lane
-    __shared__ float comp[4][4][kChunk];             // [wave][component][point of the chunk]
+    __shared__ __attribute__((aligned(16))) float comp[4][4][kChunk];   // [wave][component][point of the chunk]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_long = s->n_long, n_out = s->n_out, n_valid = s->n_valid;
     const bool has_i = stride >= 20;
@@ -260,9 +260,15 @@ __global__ __launch_bounds__(256) void k_vox_centroid_long(const unsigned char* 
             if (c + kChunk < last) fetch(c + kChunk);    // the next chunk's gathers are in flight behind this chunk's sums
             const int m = min(kChunk, last - c);
             if (lane < 4) {
+                // sixteen values per group of LDS reads (four 16-byte reads in flight), added one after the other
                 const float* col = comp[wave][lane];
+                const float4* col4 = reinterpret_cast<const float4*>(col);
                 int k = 0;
-                for (; k + 4 <= m; k += 4) { sum += col[k]; sum += col[k + 1]; sum += col[k + 2]; sum += col[k + 3]; }
+                for (; k + 16 <= m; k += 16) {
+                    const float4 a = col4[k / 4], b = col4[k / 4 + 1], c4 = col4[k / 4 + 2], d = col4[k / 4 + 3];
+                    sum += a.x; sum += a.y; sum += a.z; sum += a.w; sum += b.x; sum += b.y; sum += b.z; sum += b.w;
+                    sum += c4.x; sum += c4.y; sum += c4.z; sum += c4.w; sum += d.x; sum += d.y; sum += d.z; sum += d.w;
+                }
                 for (; k < m; k++) sum += col[k];
             }
             lds_sync();
