@@ -3,7 +3,7 @@
 //   downsampleCurrentScan()  reference src/mapOptmization.cpp:1061-1067   (VoxelGrid, leaf 0.4)
 //   extractCloud()           reference src/mapOptmization.cpp:1014-1039   (transformPointCloud of
 //                            the chosen key frames :310-329, concatenation, VoxelGrid, leaf 0.4-0.5)
-// Implemented in s2m_voxel.hip (own translation unit: it pulls in hipCUB's radix sort).
+// Implemented in s2m_voxel.hip (own translation unit; the stable radix sort of the (voxel, point) pairs is hand-written there).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>

@@ -38,13 +38,14 @@ def test_voxel_grid_bit_exact(gpu, n, leaf):
 
 def test_voxel_grid_long_runs_bit_exact(gpu):
     """Voxels that hold hundreds / thousands of points (overlapping key frames, the sensor's near field) are summed by a whole
-    wave - 64 records gathered at a time, four lanes adding one component each in the run's order - and must give the bits of
-    the oracle's sequential fp32 sums: runs of 97 .. 20 000 points next to ordinary ones, 12- and 32-byte records."""
+    wave (more than 96 points) or a whole workgroup (more than 1 024, 1 024 per round) - records gathered by all lanes, four lanes
+    adding one component each in the run's order - and must give the bits of the oracle's sequential fp32 sums: runs of
+    97 .. 20 000 points, on both sides of every boundary, next to ordinary ones, 12- and 32-byte records."""
     rng = np.random.default_rng(3)
     parts = [raw_cloud(4000)]
-    for k, m in enumerate((97, 128, 129, 640, 5000, 20000)):
+    for k, m in enumerate((97, 128, 129, 640, 1024, 1025, 2048, 2049, 3100, 5000, 20000)):
         blob = np.zeros((m, 8), np.float32)
-        blob[:, :3] = (np.array([3.0 + 2.0 * k, -4.0, 0.3]) + rng.uniform(0.01, 0.37, (m, 3))).astype(np.float32)
+        blob[:, :3] = (np.array([3.0 + 2.0 * k, -4.0 + 1.5 * (k % 3), 0.3]) + rng.uniform(0.01, 0.37, (m, 3))).astype(np.float32)
         blob[:, 3] = 1.0
         blob[:, 4] = rng.uniform(0, 255, m).astype(np.float32)
         parts.append(blob)
