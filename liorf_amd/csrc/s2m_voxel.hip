@@ -500,31 +500,39 @@ __global__ __launch_bounds__(256) void k_vox_centroid(const unsigned char* __res
 }
 
 // sum + col[0] + col[1] + ... + col[m - 1], added one after the other in that order; the next sixteen values are on their way out of
-// LDS while sixteen are added (col: 16-byte aligned, readable up to m rounded up to 16, plus 16).
+// LDS while sixteen are added (col: 16-byte aligned, readable up to m rounded up to 16, plus kAddAhead).
+constexpr int kAddAhead = 48;
 __device__ __forceinline__ float add_run(const float* col, int m, float sum)
 {
     const float4* col4 = reinterpret_cast<const float4*>(col);
+#define S2M_ADD16(q0, q1, q2, q3) \
+    sum += q0.x; sum += q0.y; sum += q0.z; sum += q0.w; sum += q1.x; sum += q1.y; sum += q1.z; sum += q1.w; \
+    sum += q2.x; sum += q2.y; sum += q2.z; sum += q2.w; sum += q3.x; sum += q3.y; sum += q3.z; sum += q3.w;
     int k = 0;
     if (m >= 16) {
+        // two groups of sixteen take turns: one is added while the other is read (the scheduling barriers keep the reads in
+        // front of the adds - left alone, the compiler moves them behind and every group waits for its own reads)
         float4 a0 = col4[0], a1 = col4[1], a2 = col4[2], a3 = col4[3];
-        for (; k + 16 <= m; k += 16) {
+        for (; k + 32 <= m; k += 32) {
             const float4 b0 = col4[k / 4 + 4], b1 = col4[k / 4 + 5], b2 = col4[k / 4 + 6], b3 = col4[k / 4 + 7];
-            sum += a0.x; sum += a0.y; sum += a0.z; sum += a0.w; sum += a1.x; sum += a1.y; sum += a1.z; sum += a1.w;
-            sum += a2.x; sum += a2.y; sum += a2.z; sum += a2.w; sum += a3.x; sum += a3.y; sum += a3.z; sum += a3.w;
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+            __builtin_amdgcn_sched_barrier(0);
+            S2M_ADD16(a0, a1, a2, a3)
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = col4[k / 4 + 8]; a1 = col4[k / 4 + 9]; a2 = col4[k / 4 + 10]; a3 = col4[k / 4 + 11];
+            __builtin_amdgcn_sched_barrier(0);
+            S2M_ADD16(b0, b1, b2, b3)
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (k + 16 <= m) { S2M_ADD16(a0, a1, a2, a3) k += 16; }
     }
+#undef S2M_ADD16
     for (; k < m; k++) sum += col[k];
     return sum;
 }
 
-// The long runs (a voxel where many key frames overlap holds hundreds of points; one near the sensor thousands): a wave per
-// voxel.  64 records at a time are gathered by the 64 lanes (one round trip) into LDS, and lanes 0..3 each add up one
-// component - x, y, z, intensity - point after point in the run's order: the same sequential fp32 sums as a single lane
-// would form, without 64 dependent gathers in a row.
 constexpr int kWaveChunk = 256;                      // wave per voxel: records per round trip, four per lane
 constexpr int kBlockPer = 4, kBlockRound = 256 * kBlockPer;   // workgroup per voxel: records per round, four per thread
-constexpr int kCentroidLds = 2 * 4 * (kBlockRound + 16);      // floats: the workgroup role's two buffers (the wave role needs half)
+constexpr int kCentroidLds = 2 * 4 * (kBlockRound + kAddAhead);      // floats: the workgroup role's two buffers (the wave role needs half)
 
 __device__ __forceinline__ void centroid_wave_role(float* __restrict__ lds, int block, int nblocks, const unsigned char* __restrict__ pts, size_t stride,
                                                    const int32_t* __restrict__ vals, const int32_t* __restrict__ heads,
@@ -532,8 +540,8 @@ __device__ __forceinline__ void centroid_wave_role(float* __restrict__ lds, int 
                                                    unsigned char* __restrict__ out, size_t out_stride)
 {
     constexpr int kChunk = kWaveChunk;
-    static_assert(4 * 4 * (kChunk + 16) <= kCentroidLds, "the wave role's rows fit the kernel's LDS");
-    float (*comp)[4][kChunk + 16] = reinterpret_cast<float (*)[4][kChunk + 16]>(lds);   // [wave][component][point of the chunk] (+16: add_run reads ahead)
+    static_assert(4 * 4 * (kChunk + kAddAhead) <= kCentroidLds, "the wave role's rows fit the kernel's LDS");
+    float (*comp)[4][kChunk + kAddAhead] = reinterpret_cast<float (*)[4][kChunk + kAddAhead]>(lds);   // [wave][component][point of the chunk] (add_run reads ahead)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_long = s->n_long, n_out = s->n_out, n_valid = s->n_valid;
     const int wofs = stride >= 20 ? 4 : 0;           // (xyz-only records: intensity reads as 0)
@@ -580,7 +588,7 @@ __device__ __forceinline__ void centroid_block_role(float* __restrict__ lds, int
                                                     unsigned char* __restrict__ out, size_t out_stride)
 {
     constexpr int kPer = kBlockPer, kRound = kBlockRound;
-    float (*comp)[4][kRound + 16] = reinterpret_cast<float (*)[4][kRound + 16]>(lds);      // [buffer][component][point of the round]
+    float (*comp)[4][kRound + kAddAhead] = reinterpret_cast<float (*)[4][kRound + kAddAhead]>(lds);      // [buffer][component][point of the round]
     const int tid = threadIdx.x;
     const int n_vlong = s->n_vlong, n_out = s->n_out, n_valid = s->n_valid;
     const int wofs = stride >= 20 ? 4 : 0;           // (xyz-only records: intensity reads as 0)
