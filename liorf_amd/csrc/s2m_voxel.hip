@@ -672,13 +672,22 @@ __global__ __launch_bounds__(256) void k_transform_frames(const unsigned char* c
     const float* t = T + 12 * lo;
     const float* p = reinterpret_cast<const float*>(src[lo] + (size_t)(i - offsets[lo]) * stride);
     const float x = p[0], y = p[1], z = p[2];
+    const float w = p[stride >= 20 ? 4 : 0];
+    const float ox = t[0] * x + t[1] * y + t[2] * z + t[3];
+    const float oy = t[4] * x + t[5] * y + t[6] * z + t[7];
+    const float oz = t[8] * x + t[9] * y + t[10] * z + t[11];
+    const float oi = stride >= 20 ? w : 0.0f;
+    if (out_stride == 32) {                        // the library's own record: two 16-byte stores
+        float4* o4 = reinterpret_cast<float4*>(out + (size_t)i * 32);
+        o4[0] = make_float4(ox, oy, oz, 1.0f);
+        o4[1] = make_float4(oi, 0.0f, 0.0f, 0.0f);
+        return;
+    }
     float* o = reinterpret_cast<float*>(out + (size_t)i * out_stride);
-    o[0] = t[0] * x + t[1] * y + t[2] * z + t[3];
-    o[1] = t[4] * x + t[5] * y + t[6] * z + t[7];
-    o[2] = t[8] * x + t[9] * y + t[10] * z + t[11];
+    o[0] = ox; o[1] = oy; o[2] = oz;
     const int words = (int)(out_stride >> 2);
     if (words > 3) o[3] = 1.0f;
-    if (words > 4) o[4] = (stride >= 20) ? p[4] : 0.0f;
+    if (words > 4) o[4] = oi;
     for (int k = 5; k < words; k++) o[k] = 0.0f;
 }
 
