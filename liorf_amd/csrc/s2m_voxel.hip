@@ -156,13 +156,9 @@ __global__ __launch_bounds__(64) void k_vox_setup(VoxSetup* s, float leaf, const
     s->mul2 = div_b[0] * div_b[1];
 }
 
-__global__ __launch_bounds__(256) void k_vox_keys(const unsigned char* __restrict__ pts, size_t stride, int n,
-                                                  const VoxSetup* __restrict__ s, uint32_t* __restrict__ keys)
+// the voxel index of a point as the sort's key (non-finite points: kInvalidKey, behind every voxel)
+__device__ __forceinline__ uint32_t voxel_key(float x, float y, float z, const VoxSetup* __restrict__ s)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* p = reinterpret_cast<const float*>(pts + (size_t)i * stride);
-    const float x = p[0], y = p[1], z = p[2];
     uint32_t key = kInvalidKey;
     if (isfinite(x) && isfinite(y) && isfinite(z)) {
         const float inv = s->inv_leaf;
@@ -172,7 +168,7 @@ __global__ __launch_bounds__(256) void k_vox_keys(const unsigned char* __restric
         key = (uint32_t)(ijk0 + ijk1 * s->mul1 + ijk2 * s->mul2);
         if (key == kInvalidKey) key = kInvalidKey - 1u;          // unreachable unless the leaf is too small
     }
-    keys[i] = key;                                  // (the value that travels with it is i: the sort's first pass supplies it)
+    return key;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -195,18 +191,38 @@ __device__ __forceinline__ unsigned long long rs_peers(uint32_t digit, unsigned 
     return peers;
 }
 
-// digit histogram of every block's tile, written bin-major: hist[bin * nblk + block]
-__global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift, int nblk, int32_t* __restrict__ hist)
+// digit histogram of every block's tile: hist[block][digit]
+// FROM_POINTS: the first pass makes the keys on the way (voxel index of every point, written to `keys_out`; the value that
+// travels with a key is the point's position, supplied by the first scatter).
+template <bool FROM_POINTS>
+__global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ keys, int n, int shift, int32_t* __restrict__ hist,
+                                                 const unsigned char* __restrict__ pts, size_t stride, const VoxSetup* __restrict__ s,
+                                                 uint32_t* __restrict__ keys_out)
 {
     __shared__ int32_t h[kRsBins];
     for (int b = threadIdx.x; b < kRsBins; b += 256) h[b] = 0;
     __syncthreads();
     const int base = blockIdx.x * kRsTile;
     uint32_t key[kRsRounds];
+    if (FROM_POINTS) {
+        float x[kRsRounds], y[kRsRounds], z[kRsRounds];
 #pragma unroll
-    for (int r = 0; r < kRsRounds; r++) {                 // all loads in flight before the first add
-        const int i = base + r * 256 + threadIdx.x;
-        key[r] = i < n ? keys[i] : 0u;
+        for (int r = 0; r < kRsRounds; r++) {             // (unconditional, clamped: all loads in flight at once)
+            const float* p = reinterpret_cast<const float*>(pts + (size_t)min(base + r * 256 + (int)threadIdx.x, n - 1) * stride);
+            x[r] = p[0]; y[r] = p[1]; z[r] = p[2];
+        }
+#pragma unroll
+        for (int r = 0; r < kRsRounds; r++) {
+            const int i = base + r * 256 + threadIdx.x;
+            key[r] = voxel_key(x[r], y[r], z[r], s);
+            if (i < n) keys_out[i] = key[r];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kRsRounds; r++) {             // all loads in flight before the first add
+            const int i = base + r * 256 + threadIdx.x;
+            key[r] = i < n ? keys[i] : 0u;
+        }
     }
 #pragma unroll
     for (int r = 0; r < kRsRounds; r++) {
@@ -214,25 +230,43 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t* __restrict__ ke
         if (i < n) atomicAdd(&h[(key[r] >> shift) & (kRsBins - 1)], 1);       // (counts: the order of the adds does not matter)
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < kRsBins; b += 256) hist[(size_t)b * nblk + blockIdx.x] = h[b];
+    for (int b = threadIdx.x; b < kRsBins; b += 256) hist[(size_t)blockIdx.x * kRsBins + b] = h[b];
 }
 
-// one wave per bin: exclusive prefix of the bin's row over the blocks, in place; the bin's total
-__global__ __launch_bounds__(64) void k_rs_scan_bins(int32_t* __restrict__ hist, int nblk, int32_t* __restrict__ bin_tot)
+// Exclusive prefix of every digit's counts over the blocks, in place, and the digit's total.  A workgroup takes 16 digits (64
+// contiguous bytes of every block's row); its 16 groups of 16 lanes share the blocks out in contiguous ranges, add their range
+// up, exchange the sums through LDS and walk the range a second time to leave the prefixes (loads independent of one another).
+constexpr int kScanDigits = 16;
+__global__ __launch_bounds__(256) void k_rs_scan_bins(int32_t* __restrict__ hist, int nblk, int32_t* __restrict__ bin_tot)
 {
-    int32_t* row = hist + (size_t)blockIdx.x * nblk;
-    const int lane = threadIdx.x;
-    int32_t carry = 0;
-    for (int c = 0; c < nblk; c += 64) {
-        const int j = c + lane;
-        const int32_t v = j < nblk ? row[j] : 0;
-        int32_t incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const int32_t o = __shfl_up(incl, off, 64); if (lane >= off) incl += o; }
-        if (j < nblk) row[j] = carry + incl - v;
-        carry += __shfl(incl, 63, 64);
+    __shared__ int32_t part[16][kScanDigits];
+    const int g = threadIdx.x >> 4, b = threadIdx.x & 15;
+    const int bin = blockIdx.x * kScanDigits + b;
+    const int per = (nblk + 15) / 16;
+    const int r0 = g * per, r1 = min(r0 + per, nblk);
+    int32_t* col = hist + bin;
+    int32_t sum = 0;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const int32_t v0 = col[(size_t)r * kRsBins], v1 = col[(size_t)(r + 1) * kRsBins], v2 = col[(size_t)(r + 2) * kRsBins], v3 = col[(size_t)(r + 3) * kRsBins];
+        sum += v0 + v1 + v2 + v3;
     }
-    if (lane == 0) bin_tot[blockIdx.x] = carry;
+    for (; r < r1; r++) sum += col[(size_t)r * kRsBins];
+    part[g][b] = sum;
+    __syncthreads();
+    int32_t run = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const int32_t p = part[k][b]; run += k < g ? p : 0; total += p; }
+    if (g == 0) bin_tot[bin] = total;
+    r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        const int32_t v0 = col[(size_t)r * kRsBins], v1 = col[(size_t)(r + 1) * kRsBins], v2 = col[(size_t)(r + 2) * kRsBins], v3 = col[(size_t)(r + 3) * kRsBins];
+        col[(size_t)r * kRsBins] = run; run += v0;
+        col[(size_t)(r + 1) * kRsBins] = run; run += v1;
+        col[(size_t)(r + 2) * kRsBins] = run; run += v2;
+        col[(size_t)(r + 3) * kRsBins] = run; run += v3;
+    }
+    for (; r < r1; r++) { const int32_t v = col[(size_t)r * kRsBins]; col[(size_t)r * kRsBins] = run; run += v; }
 }
 
 // Scatter.  Wave w of a block owns keys [base + 1024 w, base + 1024 (w + 1)), 64 consecutive ones per round, so the order of the
@@ -257,7 +291,7 @@ __global__ __launch_bounds__(256) void k_rs_scatter(const uint32_t* __restrict__
 #pragma unroll
     for (int k = 0; k < 8; k++) t8[k] = bin_tot[8 * tid + k];
 #pragma unroll
-    for (int k = 0; k < 8; k++) h8[k] = hist[(size_t)(8 * tid + k) * nblk + blockIdx.x];
+    for (int k = 0; k < 8; k++) h8[k] = hist[(size_t)blockIdx.x * kRsBins + 8 * tid + k];
     const int base = blockIdx.x * kRsTile + wave * (kRsTile / 4);
     uint32_t key[kRsRounds];
     int32_t val[kRsRounds];
@@ -743,15 +777,15 @@ hipError_t vox_downsample(VoxWorkspace* w, hipStream_t stream, const unsigned ch
     const int nbb = nb < 512 ? nb : 512;
     hipLaunchKernelGGL(k_vox_bbox, dim3(nbb), dim3(256), 0, stream, d_in, stride, ni, reinterpret_cast<uint32_t*>(rs_hist));    // (rs_hist: free until the sort)
     hipLaunchKernelGGL(k_vox_setup, dim3(1), dim3(64), 0, stream, s, leaf, reinterpret_cast<const uint32_t*>(rs_hist), nbb);
-    hipLaunchKernelGGL(k_vox_keys, dim3(nb), dim3(256), 0, stream, d_in, stride, ni, (const VoxSetup*)s, keys_a);
     VOX_TRY(hipGetLastError());
     // stable sort of (voxel index, point) by voxel index: three 11-bit passes, a -> b -> a -> b (the first takes the point's position as its value)
     for (int pass = 0; pass < 3; pass++) {
         const uint32_t* kin = (pass & 1) ? keys_b : keys_a; uint32_t* kout = (pass & 1) ? keys_a : keys_b;
         const int32_t* vin = pass == 0 ? nullptr : ((pass & 1) ? vals_b : vals_a); int32_t* vout = (pass & 1) ? vals_a : vals_b;
         const int shift = pass * kRsBits;
-        hipLaunchKernelGGL(k_rs_hist, dim3(nblk), dim3(256), 0, stream, kin, ni, shift, nblk, rs_hist);
-        hipLaunchKernelGGL(k_rs_scan_bins, dim3(kRsBins), dim3(64), 0, stream, rs_hist, nblk, rs_tot);
+        if (pass == 0) hipLaunchKernelGGL(k_rs_hist<true>, dim3(nblk), dim3(256), 0, stream, kin, ni, shift, rs_hist, d_in, stride, (const VoxSetup*)s, keys_a);
+        else hipLaunchKernelGGL(k_rs_hist<false>, dim3(nblk), dim3(256), 0, stream, kin, ni, shift, rs_hist, d_in, stride, (const VoxSetup*)s, (uint32_t*)nullptr);
+        hipLaunchKernelGGL(k_rs_scan_bins, dim3(kRsBins / kScanDigits), dim3(256), 0, stream, rs_hist, nblk, rs_tot);
         hipLaunchKernelGGL(k_rs_scatter, dim3(nblk), dim3(256), 0, stream, kin, vin, ni, shift, nblk, (const int32_t*)rs_hist, (const int32_t*)rs_tot, kout, vout);
     }
     VOX_TRY(hipGetLastError());
