@@ -2,8 +2,9 @@
 src/mapOptmization.cpp:571-586 -> pcl::IterativeClosestPoint, PCL 1.10 [ext]) through the C ABI against the
 CPU oracle.  The correspondences are identical (same fp32 distance expression, ties to the lower index); the
 centroid / covariance sums are fp64 on the device and sequential fp32 in the oracle, so the transformation
-agrees to ~1e-5 and the iteration count can differ by one when a convergence test is decided by that margin.
-PARITY UNPINNED."""
+agrees to the rounding of those sums: measured <= 1.9e-6 on every case below with equal iteration counts
+(`tools/experiments/icp_margins.py`, round 4); the bars are 1e-5 on the transformation, equal iterations.
+PARITY UNPINNED (the oracle restates PCL 1.10, which the image does not hold)."""
 import numpy as np
 import pytest
 
@@ -27,9 +28,9 @@ def test_icp_matches_oracle(gpu, n_tgt, n_src, seed):
     T, conv, fit, its = gpu.icpAlign(src, tgt, max_correspondence_distance=30.0)
     To, convo, fito, itso = O.icp_align(src, tgt, max_corr_dist=30.0)
     assert conv == convo and conv
-    assert abs(its - itso) <= 1
-    assert np.abs(T - To).max() <= 2e-4
-    assert abs(fit - fito) <= 1e-5
+    assert its == itso
+    assert np.abs(T - To).max() <= 1e-5
+    assert abs(fit - fito) <= 1e-6
     assert np.abs(T[:3, 3] - T_true[:3, 3]).max() < 0.03
 
 
@@ -39,11 +40,11 @@ def test_icp_single_iteration_and_limits(gpu):
     T, conv, fit, its = gpu.icpAlign(src, tgt, max_correspondence_distance=30.0, max_iterations=1)
     To, convo, fito, itso = O.icp_align(src, tgt, max_corr_dist=30.0, max_iter=1)
     assert its == itso == 1 and conv and convo
-    assert np.abs(T - To).max() <= 2e-5 and abs(fit - fito) <= 1e-6
+    assert np.abs(T - To).max() <= 1e-5 and abs(fit - fito) <= 5e-6
     # a tight correspondence distance keeps only close pairs (both sides the same set)
     T, conv, fit, its = gpu.icpAlign(src, tgt, max_correspondence_distance=0.5)
     To, convo, fito, itso = O.icp_align(src, tgt, max_corr_dist=0.5)
-    assert conv == convo and abs(its - itso) <= 1 and np.abs(T - To).max() <= 5e-4
+    assert conv == convo and its == itso and np.abs(T - To).max() <= 1e-5
     # nothing within reach: not converged, identity, zero iterations
     far = src.copy(); far[:, 0] += 500.0
     T, conv, fit, its = gpu.icpAlign(far, tgt, max_correspondence_distance=1.0)
@@ -52,6 +53,6 @@ def test_icp_single_iteration_and_limits(gpu):
     bad = src.copy(); bad[5, 0] = np.nan; bad[9, 2] = np.inf
     T, conv, fit, its = gpu.icpAlign(bad, tgt, max_correspondence_distance=30.0)
     To, convo, fito, itso = O.icp_align(bad, tgt, max_corr_dist=30.0)
-    assert conv == convo and np.abs(T - To).max() <= 2e-4
+    assert conv == convo and np.abs(T - To).max() <= 1e-5
     with pytest.raises(s2m.S2MError):
         gpu.icpAlign(src, tgt, max_iterations=0)
