@@ -188,8 +188,11 @@ int device_exclusive_scan(s2m_context* h, const int32_t* counts, int32_t* out, i
     if (rc) return rc;
     int32_t* sums = h->block_sums.as<int32_t>();
     hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(256), 0, h->stream, counts, out, sums, n);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sums, nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, h->stream, out, (const int32_t*)sums, n, total);
+    if (nb <= 4096) hipLaunchKernelGGL(k_scan_add_fold, dim3(nb), dim3(256), 0, h->stream, out, (const int32_t*)sums, n, total);
+    else {
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, h->stream, sums, nb);
+        hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(256), 0, h->stream, out, (const int32_t*)sums, n, total);
+    }
     S2M_HIP(h, hipGetLastError());
     return S2M_OK;
 }
@@ -197,10 +200,12 @@ int device_exclusive_scan(s2m_context* h, const int32_t* counts, int32_t* out, i
 // bounding box of the finite points (device reduction + 24-byte readback)
 int device_bbox(s2m_context* h, const unsigned char* d_pts, size_t stride, int n, float mn[3], float mx[3])
 {
-    for (int d = 0; d < 3; d++) { h->h_mm[d] = 0xffffffffu; h->h_mm[3 + d] = 0u; }
-    S2M_HIP(h, hipMemcpyAsync(h->mm.p, h->h_mm, 24, hipMemcpyHostToDevice, h->stream));
     const int blocks = std::min((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, h->stream, d_pts, stride, n, h->mm.as<uint32_t>());
+    int rc = ensure(h, h->mm, 64 + sizeof(uint32_t) * 8 * 1024);          // mm[0..5], then 8 words per workgroup from word 16 on
+    if (rc) return rc;
+    uint32_t* part = h->mm.as<uint32_t>() + 16;
+    hipLaunchKernelGGL(k_bbox, dim3(blocks), dim3(256), 0, h->stream, d_pts, stride, n, part);
+    hipLaunchKernelGGL(k_bbox_fold, dim3(1), dim3(256), 0, h->stream, (const uint32_t*)part, blocks, h->mm.as<uint32_t>());
     S2M_HIP(h, hipGetLastError());
     S2M_HIP(h, hipMemcpyAsync(h->h_mm, h->mm.p, 24, hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
@@ -841,7 +846,7 @@ int s2m_create(const s2m_params* p, s2m_handle* out)
     if (hipHostMalloc((void**)&h->h_mm, 64) != hipSuccess) return bail(S2M_ERR_HIP);
     if (hipHostMalloc((void**)&h->h_sc, sizeof(double) * 1220) != hipSuccess) return bail(S2M_ERR_HIP);
     if (ensure(h, h->state, sizeof(DevState) + sizeof(s2m_iter_trace) * kMaxIter) ||      // loop state, then the trace
-        ensure(h, h->dctx, sizeof(DevCtx)) || ensure(h, h->mm, 64) ||
+        ensure(h, h->dctx, sizeof(DevCtx)) || ensure(h, h->mm, 64 + sizeof(uint32_t) * 8 * 1024) ||
         ensure(h, h->sc_bins, sizeof(uint32_t) * 1200) || ensure(h, h->sc_out, sizeof(double) * 1220) ||
         ensure(h, h->q_counts, sizeof(int32_t) * kPolarCells))
         return bail(S2M_ERR_HIP);

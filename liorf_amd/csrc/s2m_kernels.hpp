@@ -187,9 +187,10 @@ S2M_HD inline float glibc_atanf(float x)
 // ------------------------------------------------------------------------------------------
 // index build: bounding box, cell histogram with per-point rank, exclusive scan, scatter
 // ------------------------------------------------------------------------------------------
-// mm[0..2] = ordered-uint min x,y,z ; mm[3..5] = ordered-uint max x,y,z (host initialises).
-// Grid-stride over a small grid, workgroup tree first: 6 same-address atomics per workgroup.
-__global__ __launch_bounds__(256) void k_bbox(const unsigned char* __restrict__ pts, size_t stride, int n, uint32_t* mm)
+// Bounding box of the finite coordinates, as ordered uints (min x, y, z, max x, y, z).  Every workgroup leaves its own box in
+// `part` (8 words each), k_bbox_fold puts them together: adds from every workgroup on one address are served one after the other on
+// this part (~6 ns each) - six of them from each of 782 workgroups were 15 of this kernel's 20 us at 200 k points.
+__global__ __launch_bounds__(256) void k_bbox(const unsigned char* __restrict__ pts, size_t stride, int n, uint32_t* __restrict__ part)
 {
     __shared__ float smn[4][3], smx[4][3];
     float mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
@@ -217,10 +218,39 @@ __global__ __launch_bounds__(256) void k_bbox(const unsigned char* __restrict__ 
     __syncthreads();
     if (threadIdx.x < 3) {
         const int d = threadIdx.x;
-        float a = fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d]));
-        float b = fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]));
-        atomicMin(&mm[d], f2ord(a));
-        atomicMax(&mm[3 + d], f2ord(b));
+        const float a = fminf(fminf(smn[0][d], smn[1][d]), fminf(smn[2][d], smn[3][d]));
+        const float b = fmaxf(fmaxf(smx[0][d], smx[1][d]), fmaxf(smx[2][d], smx[3][d]));
+        part[8 * blockIdx.x + d] = a <= b ? f2ord(a) : 0xffffffffu;          // (no finite value: the neutral elements)
+        part[8 * blockIdx.x + 3 + d] = a <= b ? f2ord(b) : 0u;
+    }
+}
+// mm[0..2] = min, mm[3..5] = max over the workgroups' boxes (0xffffffff / 0 where no coordinate was finite)
+__global__ __launch_bounds__(256) void k_bbox_fold(const uint32_t* __restrict__ part, int nparts, uint32_t* __restrict__ mm)
+{
+    __shared__ uint32_t slo[4][3], shi[4][3];
+    uint32_t lo[3] = { 0xffffffffu, 0xffffffffu, 0xffffffffu }, hi[3] = { 0u, 0u, 0u };
+    for (int b = threadIdx.x; b < nparts; b += 256) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) { lo[d] = min(lo[d], part[8 * b + d]); hi[d] = max(hi[d], part[8 * b + 3 + d]); }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            lo[d] = min(lo[d], (uint32_t)__shfl_down((int)lo[d], off, 64));
+            hi[d] = max(hi[d], (uint32_t)__shfl_down((int)hi[d], off, 64));
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) { slo[wave][d] = lo[d]; shi[wave][d] = hi[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        mm[d] = min(min(slo[0][d], slo[1][d]), min(slo[2][d], slo[3][d]));
+        mm[3 + d] = max(max(shi[0][d], shi[1][d]), max(shi[2][d], shi[3][d]));
     }
 }
 
@@ -457,6 +487,24 @@ __global__ __launch_bounds__(256) void k_scan_add(int32_t* __restrict__ out, con
 {
     const int base = blockIdx.x * 1024 + threadIdx.x * 4;
     const int32_t off = block_sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (base + k < n) out[base + k] += off;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total;
+}
+
+// k_scan_sums and k_scan_add in one launch for grids of up to a few thousand workgroups: every workgroup adds up the sums of the
+// workgroups before it for itself (block_sums as k_scan_local left them)
+__global__ __launch_bounds__(256) void k_scan_add_fold(int32_t* __restrict__ out, const int32_t* __restrict__ block_sums, int n, int total)
+{
+    __shared__ int32_t wsum[4];
+    int32_t before = 0;
+    for (int j = threadIdx.x; j < (int)blockIdx.x; j += 256) before += block_sums[j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = before;
+    __syncthreads();
+    const int32_t off = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int base = blockIdx.x * 1024 + threadIdx.x * 4;
 #pragma unroll
     for (int k = 0; k < 4; k++) if (base + k < n) out[base + k] += off;
     if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = total;
