@@ -3,7 +3,7 @@ src/mapOptmization.cpp:571-586 -> pcl::IterativeClosestPoint, PCL 1.10 [ext]) th
 CPU oracle.  The correspondences are identical (same fp32 distance expression, ties to the lower index); the
 centroid / covariance sums are fp64 on the device and sequential fp32 in the oracle, so the transformation
 agrees to the rounding of those sums: measured <= 1.9e-6 on every case below with equal iteration counts
-(`tools/experiments/icp_margins.py`, round 4); the bars are 1e-5 on the transformation, equal iterations.
+(`tests/tools/icp_margins.py`, round 4); the bars are 1e-5 on the transformation, equal iterations.
 PARITY UNPINNED (the oracle restates PCL 1.10, which the image does not hold)."""
 import numpy as np
 import pytest
