@@ -1912,15 +1912,13 @@ int s2m_sc_detect_loop(s2m_handle h, int32_t* loop_id, float* yaw_diff_rad, s2m_
     if (h->sc_counter % TREE_MAKING_PERIOD == 0) h->sc_n_search = h->sc_n - NUM_EXCLUDE_RECENT;
     h->sc_counter = h->sc_counter + 1;
     S2M_HIP(h, hipSetDevice(h->device));
-    int rc = ensure(h, h->sc_res, sizeof(ScDetectOut));
-    if (rc) return rc;
+    // the kernel writes its 48-byte result straight into the pinned staging block (host-coherent memory the device can address):
+    // a copy behind the kernel would be a second trip through the queue, and one to pageable memory ~50 us more
+    static_assert(sizeof(ScDetectOut) <= sizeof(double) * 1220, "the result fits the pinned ScanContext staging block");
     hipLaunchKernelGGL(k_sc_detect, dim3(1), dim3(kScThreads), 0, h->stream, (const double*)h->sc_store_desc.as<double>(),
                        (const float*)h->sc_store_ring.as<float>(), (const double*)h->sc_store_sector.as<double>(),
-                       (int)h->sc_n, (int)h->sc_n_search, h->sc_res.as<ScDetectOut>());
+                       (int)h->sc_n, (int)h->sc_n_search, reinterpret_cast<ScDetectOut*>(h->h_sc));
     S2M_HIP(h, hipGetLastError());
-    // (into the pinned staging block: a copy to pageable memory goes through the runtime's own staging and costs ~50 us more)
-    static_assert(sizeof(ScDetectOut) <= sizeof(double) * 1220, "the result fits the pinned ScanContext staging block");
-    S2M_HIP(h, hipMemcpyAsync(h->h_sc, h->sc_res.p, sizeof(ScDetectOut), hipMemcpyDeviceToHost, h->stream));
     S2M_HIP(h, hipStreamSynchronize(h->stream));
     ScDetectOut o;
     memcpy(&o, h->h_sc, sizeof(o));

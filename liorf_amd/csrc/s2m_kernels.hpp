@@ -1601,34 +1601,49 @@ __global__ __launch_bounds__(kScThreads) void k_sc_append(const double* __restri
 }
 
 struct ScShared {
+    double v1[S2M_SC_NUM_SECTOR], v2[S2M_SC_NUM_SECTOR]; // the two sector keys, staged
     double vnorm[S2M_SC_NUM_SECTOR];                     // fastAlignUsingVkey: ||vkey1 - circshift(vkey2, s)||
     double sim[kScShifts][S2M_SC_NUM_SECTOR];            // per (shift, sector): cosine similarity
     int    eff[kScShifts][S2M_SC_NUM_SECTOR];            // ... and whether the sector pair counts
     double dist[kScShifts];
     int    shifts[kScShifts];
+    double dist_out;                                     // the result: distance and the shift it was found at
+    int    shift_out;
 };
 
-// distanceBtnScanContext(sc1, sc2) (:116-148) by one workgroup; result valid in thread 0.
-__device__ __forceinline__ void sc_distance_block(const double* __restrict__ sc1, const double* __restrict__ v1,
-                                                  const double* __restrict__ sc2, const double* __restrict__ v2,
-                                                  ScShared& sh, double& dist_out, int& shift_out)
+// distanceBtnScanContext(query, cand[c]) (:116-148) for NC candidates side by side by one workgroup: every phase of the
+// reference's function is spread over (candidate, shift) or (candidate, shift, sector) tasks, every sum is taken by one thread
+// from left to right like the oracle's.  `cand` lives in LDS; results in sh[c].dist_out / .shift_out, valid after the call.
+template <int NC>
+__device__ __forceinline__ void sc_distance_block(const double* __restrict__ store_desc, const double* __restrict__ store_sector,
+                                                  int q, const int* cand, ScShared* sh)
 {
     constexpr int NR = S2M_SC_NUM_RING, NS = S2M_SC_NUM_SECTOR;
     const int t = threadIdx.x;
+    const double* __restrict__ sc1 = store_desc + (size_t)q * NR * NS;
     __syncthreads();                                     // the scratch may still be read from a previous call
-    if (t < NS) {                                        // fastAlignUsingVkey (:94-113), one shift per thread
-        double a = 0.0;
-        for (int j = 0; j < NS; j++) {
-            const double d = v1[j] - v2[(j - t + NS) % NS];
-            a += d * d;
-        }
-        sh.vnorm[t] = sqrt(a);
+    for (int task = t; task < NC * NS; task += kScThreads) {
+        const int c = task / NS, j = task - c * NS;
+        sh[c].v1[j] = store_sector[(size_t)q * NS + j];
+        sh[c].v2[j] = store_sector[(size_t)cand[c] * NS + j];
     }
     __syncthreads();
-    if (t == 0) {
+    for (int task = t; task < NC * NS; task += kScThreads) {              // fastAlignUsingVkey (:94-113), one shift per task
+        const int c = task / NS, s = task - c * NS;
+        double a = 0.0;
+        for (int j = 0; j < NS; j++) {
+            int j2 = j - s; j2 += (j2 < 0) ? NS : 0;
+            const double d = sh[c].v1[j] - sh[c].v2[j2];
+            a += d * d;
+        }
+        sh[c].vnorm[s] = sqrt(a);
+    }
+    __syncthreads();
+    if (t < NC) {
+        ScShared& m = sh[t];
         int a0 = 0;
         double best = 10000000;
-        for (int s = 0; s < NS; s++) if (sh.vnorm[s] < best) { a0 = s; best = sh.vnorm[s]; }
+        for (int s = 0; s < NS; s++) if (m.vnorm[s] < best) { a0 = s; best = m.vnorm[s]; }
         // search space a0, a0 +- 1..3 (mod 60), ascending (:122-129)
         int sp[kScShifts];
         sp[0] = a0;
@@ -1639,36 +1654,42 @@ __device__ __forceinline__ void sc_distance_block(const double* __restrict__ sc1
             while (b >= 0 && sp[b] > v) { sp[b + 1] = sp[b]; b--; }
             sp[b + 1] = v;
         }
-        for (int k = 0; k < kScShifts; k++) sh.shifts[k] = sp[k];
+        for (int k = 0; k < kScShifts; k++) m.shifts[k] = sp[k];
     }
     __syncthreads();
-    for (int task = t; task < kScShifts * NS; task += kScThreads) {       // distDirectSC (:69-91), one sector pair per task
-        const int k = task / NS, j = task - k * NS;
-        const int j2 = (j - sh.shifts[k] + NS) % NS;                      // circshift (:39-59)
+    for (int task = t; task < NC * kScShifts * NS; task += kScThreads) {  // distDirectSC (:69-91), one sector pair per task
+        const int c = task / (kScShifts * NS), rem = task - c * (kScShifts * NS);
+        const int k = rem / NS, j = rem - k * NS;
+        int j2 = j - sh[c].shifts[k]; j2 += (j2 < 0) ? NS : 0;            // circshift (:39-59)
+        const double* __restrict__ sc2 = store_desc + (size_t)cand[c] * NR * NS;
         double n1 = 0.0, n2 = 0.0, dot = 0.0;
+#pragma unroll
         for (int r = 0; r < NR; r++) {
             const double a = sc1[r * NS + j], b = sc2[r * NS + j2];
             n1 += a * a; n2 += b * b; dot += a * b;
         }
         n1 = sqrt(n1); n2 = sqrt(n2);
         const bool skip = (n1 == 0) | (n2 == 0);
-        sh.eff[k][j] = skip ? 0 : 1;
-        sh.sim[k][j] = skip ? 0.0 : dot / (n1 * n2);
+        sh[c].eff[k][j] = skip ? 0 : 1;
+        sh[c].sim[k][j] = skip ? 0.0 : dot / (n1 * n2);
     }
     __syncthreads();
-    if (t < kScShifts) {
+    if (t < NC * kScShifts) {
+        const int c = t / kScShifts, k = t - c * kScShifts;
         int num_eff = 0;
         double sum = 0;
-        for (int j = 0; j < NS; j++) if (sh.eff[t][j]) { sum = sum + sh.sim[t][j]; num_eff = num_eff + 1; }
-        sh.dist[t] = 1.0 - sum / (double)num_eff;         // 0/0 = NaN when no sector counts, as in the reference
+        for (int j = 0; j < NS; j++) if (sh[c].eff[k][j]) { sum = sum + sh[c].sim[k][j]; num_eff = num_eff + 1; }
+        sh[c].dist[k] = 1.0 - sum / (double)num_eff;      // 0/0 = NaN when no sector counts, as in the reference
     }
     __syncthreads();
-    if (t == 0) {
+    if (t < NC) {
+        ScShared& m = sh[t];
         int argmin_shift = 0;
         double min_sc_dist = 10000000;
-        for (int k = 0; k < kScShifts; k++) if (sh.dist[k] < min_sc_dist) { argmin_shift = sh.shifts[k]; min_sc_dist = sh.dist[k]; }
-        dist_out = min_sc_dist; shift_out = argmin_shift;
+        for (int k = 0; k < kScShifts; k++) if (m.dist[k] < min_sc_dist) { argmin_shift = m.shifts[k]; min_sc_dist = m.dist[k]; }
+        m.dist_out = min_sc_dist; m.shift_out = argmin_shift;
     }
+    __syncthreads();
 }
 
 // distanceBtnScanContext of descriptor `query` against cand[0..m): one workgroup per candidate
@@ -1676,37 +1697,56 @@ __global__ __launch_bounds__(kScThreads) void k_sc_distance_batch(const double* 
                                                                   int query, const int32_t* __restrict__ cand, double* __restrict__ dist,
                                                                   int32_t* __restrict__ shift)
 {
-    constexpr int NR = S2M_SC_NUM_RING, NS = S2M_SC_NUM_SECTOR;
-    __shared__ ScShared sh;
-    const int c = cand[blockIdx.x];
-    double d = 0.0; int s = 0;
-    sc_distance_block(store_desc + (size_t)query * NR * NS, store_sector + (size_t)query * NS,
-                      store_desc + (size_t)c * NR * NS, store_sector + (size_t)c * NS, sh, d, s);
-    if (threadIdx.x == 0) { dist[blockIdx.x] = d; shift[blockIdx.x] = s; }
+    __shared__ ScShared sh[1];
+    __shared__ int s_cand[1];
+    if (threadIdx.x == 0) s_cand[0] = cand[blockIdx.x];
+    __syncthreads();
+    sc_distance_block<1>(store_desc, store_sector, query, s_cand, sh);
+    if (threadIdx.x == 0) { dist[blockIdx.x] = sh[0].dist_out; shift[blockIdx.x] = sh[0].shift_out; }
 }
 
 // detectLoopClosureID (:253-344) for the newest descriptor (index n_total - 1) against the ring keys
-// [0, n_search) (the contents of the reference's kd-tree at its last rebuild).
+// [0, n_search) (the contents of the reference's kd-tree at its last rebuild).  One workgroup: every thread keeps the three
+// nearest of its share of the keys, the lists are merged by a butterfly inside each wave and by one thread over the four waves
+// (order: distance, then index - the lower index wins a tie, whoever held it), then the three candidates are compared side by
+// side.  `out` may be pinned host memory (the result is 48 bytes: written where the host reads it, no copy behind the kernel).
+__device__ __forceinline__ bool sc_near_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+__device__ __forceinline__ void sc_near_insert(float (&bd)[3], int (&bi)[3], float d, int i)
+{
+    if (sc_near_less(d, i, bd[2], bi[2])) {
+        bd[2] = d; bi[2] = i;
+        if (sc_near_less(bd[2], bi[2], bd[1], bi[1])) { const float a = bd[1]; bd[1] = bd[2]; bd[2] = a; const int b2 = bi[1]; bi[1] = bi[2]; bi[2] = b2; }
+        if (sc_near_less(bd[1], bi[1], bd[0], bi[0])) { const float a = bd[0]; bd[0] = bd[1]; bd[1] = a; const int b2 = bi[0]; bi[0] = bi[1]; bi[1] = b2; }
+    }
+}
+
 __global__ __launch_bounds__(kScThreads) void k_sc_detect(const double* __restrict__ store_desc, const float* __restrict__ store_ring,
                                                           const double* __restrict__ store_sector, int n_total, int n_search,
                                                           ScDetectOut* __restrict__ out)
 {
-    constexpr int NR = S2M_SC_NUM_RING, NS = S2M_SC_NUM_SECTOR;
-    __shared__ ScShared sh;
-    __shared__ float s_d2[kScThreads][3];
-    __shared__ int   s_ix[kScThreads][3];
+    constexpr int NR = S2M_SC_NUM_RING;
+    static_assert(NR % 4 == 0, "ring keys are read four floats at a time");
+    __shared__ ScShared sh[3];
+    __shared__ float s_d2[kScThreads / 64][3];
+    __shared__ int   s_ix[kScThreads / 64][3];
     __shared__ int   s_cand[3];
     const int t = threadIdx.x, q = n_total - 1;
     // exact 3-NN over the fp32 ring keys, accumulation order of nanoflann's L2_Adaptor (groups of four);
     // ties go to the lower index
     float bd[3] = { INFINITY, INFINITY, INFINITY };
     int bi[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff };
-    const float* qk = store_ring + (size_t)q * NR;
+    float4 qk[NR / 4];
+#pragma unroll
+    for (int g = 0; g < NR / 4; g++) qk[g] = reinterpret_cast<const float4*>(store_ring + (size_t)q * NR)[g];
     for (int i = t; i < n_search; i += kScThreads) {
-        const float* b = store_ring + (size_t)i * NR;
+        const float4* b = reinterpret_cast<const float4*>(store_ring + (size_t)i * NR);      // (rows are 80 bytes: 16-byte aligned)
+        float4 bk[NR / 4];
+#pragma unroll
+        for (int g = 0; g < NR / 4; g++) bk[g] = b[g];
         float result = 0.0f;
-        for (int d = 0; d < NR; d += 4) {
-            const float d0 = qk[d] - b[d], d1 = qk[d + 1] - b[d + 1], d2 = qk[d + 2] - b[d + 2], d3 = qk[d + 3] - b[d + 3];
+#pragma unroll
+        for (int g = 0; g < NR / 4; g++) {
+            const float d0 = qk[g].x - bk[g].x, d1 = qk[g].y - bk[g].y, d2 = qk[g].z - bk[g].z, d3 = qk[g].w - bk[g].w;
             result += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
         }
         if (result < bd[2]) {                             // i ascends per thread: an equal distance stays behind
@@ -1715,22 +1755,22 @@ __global__ __launch_bounds__(kScThreads) void k_sc_detect(const double* __restri
             if (bd[1] < bd[0]) { const float a = bd[0]; bd[0] = bd[1]; bd[1] = a; const int b2 = bi[0]; bi[0] = bi[1]; bi[1] = b2; }
         }
     }
-    for (int k = 0; k < 3; k++) { s_d2[t][k] = bd[k]; s_ix[t][k] = bi[k]; }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {              // both partners end with the same three
+        float pd[3]; int pi[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { pd[k] = __shfl_xor(bd[k], off, 64); pi[k] = __shfl_xor(bi[k], off, 64); }
+#pragma unroll
+        for (int k = 0; k < 3; k++) sc_near_insert(bd, bi, pd[k], pi[k]);
+    }
+    if ((t & 63) == 0)
+        for (int k = 0; k < 3; k++) { s_d2[t >> 6][k] = bd[k]; s_ix[t >> 6][k] = bi[k]; }
     __syncthreads();
     if (t == 0) {
         float fd[3] = { INFINITY, INFINITY, INFINITY };
         int fi[3] = { 0x7fffffff, 0x7fffffff, 0x7fffffff };
-        for (int u = 0; u < kScThreads; u++)
-            for (int k = 0; k < 3; k++) {
-                const float d = s_d2[u][k]; const int ix = s_ix[u][k];
-                if (ix == 0x7fffffff) continue;
-                int pos = 3;
-                while (pos > 0 && (fd[pos - 1] > d || (fd[pos - 1] == d && fi[pos - 1] > ix))) pos--;
-                if (pos < 3) {
-                    for (int m = 2; m > pos; m--) { fd[m] = fd[m - 1]; fi[m] = fi[m - 1]; }
-                    fd[pos] = d; fi[pos] = ix;
-                }
-            }
+        for (int u = 0; u < kScThreads / 64; u++)
+            for (int k = 0; k < 3; k++) sc_near_insert(fd, fi, s_d2[u][k], s_ix[u][k]);
         for (int k = 0; k < 3; k++) {
             const bool have = fi[k] != 0x7fffffff;        // fewer keys than candidates: index 0 (:289 zero-initialised)
             s_cand[k] = have ? fi[k] : 0;
@@ -1739,16 +1779,12 @@ __global__ __launch_bounds__(kScThreads) void k_sc_detect(const double* __restri
         }
     }
     __syncthreads();
-    double min_dist = 10000000;
-    int nn_align = 0, nn_idx = 0;
-    for (int c = 0; c < 3; c++) {                         // :302-316
-        double d = 0.0; int s = 0;
-        const int ci = s_cand[c];
-        sc_distance_block(store_desc + (size_t)q * NR * NS, store_sector + (size_t)q * NS,
-                          store_desc + (size_t)ci * NR * NS, store_sector + (size_t)ci * NS, sh, d, s);
-        if (t == 0 && d < min_dist) { min_dist = d; nn_align = s; nn_idx = ci; }
-    }
+    sc_distance_block<3>(store_desc, store_sector, q, s_cand, sh);
     if (t == 0) {
+        double min_dist = 10000000;
+        int nn_align = 0, nn_idx = 0;
+        for (int c = 0; c < 3; c++)                        // :302-316
+            if (sh[c].dist_out < min_dist) { min_dist = sh[c].dist_out; nn_align = sh[c].shift_out; nn_idx = s_cand[c]; }
         out->min_dist = min_dist; out->nn_idx = nn_idx; out->nn_align = nn_align;
         out->loop_id = (min_dist < 0.3) ? nn_idx : -1;    // SC_DIST_THRES (Scancontext.h:95)
         out->yaw_diff_rad = (float)((double)(float)((double)nn_align * (360.0 / 60.0)) * M_PI / 180.0);   // deg2rad(float) (:17-20, :338)
