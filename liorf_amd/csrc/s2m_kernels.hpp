@@ -622,7 +622,7 @@ __device__ __forceinline__ void chunk_table_body(const int32_t* __restrict__ par
                                                  int32_t* __restrict__ factor, DevState* __restrict__ st)
 {
     __shared__ int32_t wsum[16];
-    __shared__ int32_t carry_s, tot_s[3], base_s;
+    __shared__ int32_t carry_s, tot_s[3], base_s, pol_s[9];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // One workgroup per CU runs measurably faster than two (steady launch 25 vs 27.7 us at 120k points): the
     // density wishes are dropped if they alone would push the grid over one workgroup on each of the 256 CUs.
@@ -640,22 +640,50 @@ __device__ __forceinline__ void chunk_table_body(const int32_t* __restrict__ par
         use_factor = !(base_s <= kOnePerCu && tot_s[0] > kOnePerCu);
         __syncthreads();
     }
-    // pass A: total waves wished for when parts are capped at 8, 4, 2
-    int t8 = 0, t4 = 0, t2 = 0;
-    auto wish = [&](int c) { return min(8, parts[c] * (use_factor ? max(factor[c], 1) : 1)); };
-    for (int c = threadIdx.x; c < n_chunks; c += 1024) { const int p = wish(c); t8 += p; t4 += min(p, 4); t2 += min(p, 2); }
+    // pass A: total waves wished for under each way of scaling the wishes back, mildest first.  The density wishes are the ones
+    // that count - a launch lasts as long as its slowest wave, and the slowest are the waves whose box streams thousands of map
+    // points - so the chunks that asked for the finest cut keep it longest: 0 every wish; 1 / 2 density wishes below 4 / below 8
+    // dropped; 3..5 as 2 with the other chunks capped at 4, 2, 1; 6..8 as 2 with every chunk capped at 4, 2, 1.
+    // (Scaling every wish back alike left the heaviest chunks of a dense map at two parts: dense1m launch 0, slowest wave 223 us.)
+    constexpr int kPolicies = 9;
+    auto wish_under = [&](int c, int pol) {
+        const int f = use_factor ? max(factor[c], 1) : 1;
+        const bool heavy = f >= 8;
+        const int fe = (pol == 0) ? f : ((pol == 1) ? (f >= 4 ? f : 1) : (heavy ? f : 1));
+        const int w = min(8, parts[c] * fe);
+        const int cap = (pol <= 2) ? 8 : ((pol <= 5) ? (heavy ? 8 : (32 >> pol)) : (256 >> pol));      // 3,4,5 -> 4,2,1; 6,7,8 -> 4,2,1
+        return min(w, cap);
+    };
+    int tp[kPolicies];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { t8 += __shfl_xor(t8, off, 64); t4 += __shfl_xor(t4, off, 64); t2 += __shfl_xor(t2, off, 64); }
-    if (threadIdx.x == 0) { carry_s = 0; tot_s[0] = 0; tot_s[1] = 0; tot_s[2] = 0; }
+    for (int k = 0; k < kPolicies; k++) tp[k] = 0;
+    for (int c = threadIdx.x; c < n_chunks; c += 1024) {
+#pragma unroll
+        for (int k = 0; k < kPolicies; k++) tp[k] += wish_under(c, k);
+    }
+#pragma unroll
+    for (int k = 0; k < kPolicies; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) tp[k] += __shfl_xor(tp[k], off, 64);
+    }
+    if (threadIdx.x == 0) carry_s = 0;
+    if (threadIdx.x < kPolicies) pol_s[threadIdx.x] = 0;
     __syncthreads();
-    if (lane == 0) { atomicAdd(&tot_s[0], t8); atomicAdd(&tot_s[1], t4); atomicAdd(&tot_s[2], t2); }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < kPolicies; k++) atomicAdd(&pol_s[k], tp[k]);
+    }
     __syncthreads();
     // The grid holds at most two 8-wave workgroups per CU at once (512 workgroups = 4096 waves); a few waves
     // beyond that cost a whole extra round.  A scan whose unsplit chunks still fit gives up splits before it
     // gives up that (262 144 points = 4096 chunks exactly: 20.5k -> 22.2k LM iterations/s).
     constexpr int kTwoPerCu = 2 * kOnePerCu;
     const int cap_eff = (n_chunks <= kTwoPerCu) ? min(capacity, kTwoPerCu) : capacity;
-    const int pcap = (tot_s[0] <= cap_eff) ? 8 : ((tot_s[1] <= cap_eff) ? 4 : ((tot_s[2] <= cap_eff) ? 2 : 1));
+    int pol = kPolicies - 1;
+#pragma unroll
+    for (int k = kPolicies - 2; k >= 0; k--) if (pol_s[k] <= cap_eff) pol = k;
+    auto wish = [&](int c) { return wish_under(c, pol); };
+    constexpr int pcap = 8;
     // pass B: scan and emit
     for (int base = 0; base < n_chunks; base += 1024) {
         const int c = base + threadIdx.x;
