@@ -102,3 +102,38 @@ def test_add_scan_path_matches_oracle(gpu):
             found += lid >= 0
     assert found >= 1
     orc.close()
+
+
+def test_detect_with_duplicated_key_frames_in_a_large_store(gpu):
+    """A robot standing still stores the same descriptor again and again: ring-key distances tie exactly, and in a
+    store of ~700 key frames the tied keys sit in different lanes, different waves and different strides of
+    k_sc_detect's search (lane = index mod 256).  The 3-NN lists are merged by a butterfly inside each wave and by
+    one thread over the waves; the order is (distance, index), so the candidates have to be the oracle's - ties to
+    the lower index - and everything behind them (shift, distance, loop id) bit-identical."""
+    rng = np.random.default_rng(23)
+    base = make_descriptors(60, seed=9)
+    descs = []
+    for k in range(700):
+        if k % 7 in (3, 4) or 250 <= k < 262 or 505 <= k < 512:
+            descs.append(base[(k // 64) % 60].copy())           # exact copies, spread over lanes, waves and strides
+        else:
+            d = base[int(rng.integers(0, 60))].copy()
+            descs.append(revisit(d, int(rng.integers(0, 60)), float(rng.uniform(0.0, 0.05)), int(rng.integers(0, 1 << 30))))
+    gpu.scReset()
+    orc = O.SCManager()
+    ties = 0
+    for i, d in enumerate(descs):
+        gpu.scAddDescriptor(d)
+        orc.add_descriptor(d)
+        lid, yaw, m = gpu.detectLoopClosureID()
+        olid, oyaw, om = orc.detectLoopClosureID()
+        assert lid == olid and np.float32(yaw) == np.float32(oyaw), (i, lid, olid)
+        if i >= 30:
+            assert list(m.cand_idx) == om["cand_idx"], (i, list(m.cand_idx), om["cand_idx"])
+            d2 = np.array(m.cand_d2, np.float32)
+            assert np.array_equal(d2.view(np.uint32), np.array(om["cand_d2"], np.float32).view(np.uint32)), i
+            assert m.nn_idx == om["nn_idx"] and m.nn_align == om["nn_align"], i
+            assert np.float64(m.min_dist).view(np.uint64) == np.float64(om["min_dist"]).view(np.uint64), i
+            ties += int(d2[0] == d2[1] or d2[1] == d2[2])
+    assert ties >= 100, ties
+    orc.close()
