@@ -674,11 +674,12 @@ __device__ __forceinline__ void chunk_table_body(const int32_t* __restrict__ par
         for (int k = 0; k < kPolicies; k++) atomicAdd(&pol_s[k], tp[k]);
     }
     __syncthreads();
-    // The grid holds at most two 8-wave workgroups per CU at once (512 workgroups = 4096 waves); a few waves
-    // beyond that cost a whole extra round.  A scan whose unsplit chunks still fit gives up splits before it
-    // gives up that (262 144 points = 4096 chunks exactly: 20.5k -> 22.2k LM iterations/s).
-    constexpr int kTwoPerCu = 2 * kOnePerCu;
-    const int cap_eff = (n_chunks <= kTwoPerCu) ? min(capacity, kTwoPerCu) : capacity;
+    // (Until the last session of round 4 a scan whose unsplit chunks fitted the 4 096 co-resident waves gave up every split before
+    // it gave up that - measured on the round-2 kernel, 262 144 points = 4 096 chunks exactly: 20.5 k -> 22.2 k LM iterations/s.
+    // With the rebuilt search the opposite holds: ouster128's launches 0-3 272 -> 222 us with its scattered and dense chunks split,
+    // launch 1 below launch 0 at last, and the 30-launch loop no slower, 0.70 ms either way - the second entry some waves take in
+    // a steady launch costs less than the stragglers of the cold ones.  The table's own capacity is the only limit now.)
+    const int cap_eff = capacity;
     int pol = kPolicies - 1;
 #pragma unroll
     for (int k = kPolicies - 2; k >= 0; k--) if (pol_s[k] <= cap_eff) pol = k;
